@@ -1,0 +1,51 @@
+"""Helpers to load the committed golden vectors (tests/golden/*.npz, made by make_golden.py)."""
+import glob
+import json
+import os
+
+import numpy as np
+import torch
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _t(a, dtype):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype == "bfloat16":
+        t = t.view(torch.bfloat16)
+    return t
+
+
+def load_case(path):
+    z = np.load(path)
+    meta = json.loads(str(z["meta"]))
+    dtype = meta.get("dtype", "float32")
+    case = dict(meta=meta, name=meta["name"])
+    x = _t(z["x_thwc"], dtype)                   # [T, H, W, C] memory
+    case["x"] = x.permute(0, 3, 1, 2)            # production layout: [T, C, H, W] view
+    case["feat"] = _t(z["feat"], dtype)
+    if meta["fn"] == "quadtree":
+        case["npatch"] = torch.from_numpy(z["npatch"])
+        case["tlbr"] = torch.from_numpy(z["tlbr"])
+    else:
+        case["idx"] = torch.from_numpy(z["idx"])
+    return case
+
+
+def case_paths(prefixes):
+    out = []
+    for p in sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))):
+        if os.path.basename(p).startswith(tuple(prefixes)):
+            out.append(p)
+    return out
+
+
+def kat():
+    with open(os.path.join(GOLDEN_DIR, "kat.json")) as f:
+        return json.load(f)
+
+
+def quadtree_kwargs(meta):
+    kw = dict(meta["kw"])
+    thr = kw.pop("threshold")
+    return thr, kw
