@@ -1,0 +1,127 @@
+/*
+ * libsttm_hip.so -- C ABI of the MI355X (gfx950) implementation of STTM's token-merging hot path.
+ *
+ * The reference (HYUNJS/STTM) is pure Python/PyTorch and has no FFI of its own; the boundary its callers
+ * see is the pair of L1 functions
+ *     get_quadtree_features(...)   token_merging_utils/quadtree_interface.py:5-13
+ *     get_tome_features(...)       token_merging_utils/tome_interface.py:3-9
+ * called from the patched decoder forward
+ *     token_merging_monkey_patch/quadtree_attn_monkey_patch.py:100-101
+ *     token_merging_qwen2vl_monkey_patch/quadtree_attn_monkey_patch.py:100-101
+ *     token_merging_monkey_patch/tome_attn_monkey_patch.py:99
+ * The entry points below are what a ctypes binding of those two functions needs (see INTEGRATION.md for
+ * the stub); `sttm_amd/quadtree_interface.py` and `sttm_amd/tome_interface.py` are that binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - the library never allocates device memory and never synchronises: the caller owns all buffers
+ *     (sized with the *_workspace_bytes / worst-case rules below) and the stream;
+ *   - return value 0 = success, < 0 = error (sttm_last_error() returns a thread-local message);
+ *   - dtype codes: 0 = float32, 1 = bfloat16, 2 = float16;
+ *   - strides are in ELEMENTS of the logical [T, C, H, W] tensor the reference API receives; the
+ *     production layout is a channels-last view (stride_c == 1), which is required here.
+ */
+#ifndef STTM_HIP_H
+#define STTM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STTM_ABI_VERSION 1
+
+#define STTM_F32 0
+#define STTM_BF16 1
+#define STTM_F16 2
+
+/* error codes */
+#define STTM_OK 0
+#define STTM_ERR_ARG (-1)        /* bad argument (message says which)                               */
+#define STTM_ERR_UNSUPPORTED (-2)/* valid for the reference, not implemented on the device path     */
+#define STTM_ERR_LAUNCH (-3)     /* HIP reported a launch error                                     */
+#define STTM_ERR_INDEX (-4)      /* root_level out of range (the reference raises IndexError)       */
+#define STTM_ERR_PARITY (-5)     /* weighted_avg on a mixed-parity level (reference: RuntimeError)  */
+
+/* slots of the int32 `counts` array written by sttm_quadtree_merge (device memory, >= 8 ints) */
+#define STTM_CNT_NODES 0      /* N  : nodes after the spatial stage                                  */
+#define STTM_CNT_CANDIDATES 1 /* L  : cross-frame candidate pairs                                    */
+#define STTM_CNT_EDGES 2      /* L' : pairs kept by the cosine filter                                */
+#define STTM_CNT_OUT 3        /* N' : merged tokens written to the outputs                           */
+#define STTM_CNT_ITERS 4      /* label-propagation iterations                                        */
+#define STTM_CNT_OVERFLOW 5   /* != 0 : an internal list overflowed (never expected; outputs invalid)*/
+#define STTM_CNT_SLOTS 8
+
+int sttm_abi_version(void);
+const char* sttm_last_error(void);
+
+/* Number of pyramid levels the reference would build for this grid/root_level
+ * (quadtree_builder.py:101-117), or a negative error code (STTM_ERR_INDEX / STTM_ERR_ARG). */
+int sttm_quadtree_num_levels(int H, int W, int root_level);
+
+/* Bytes of scratch `sttm_quadtree_merge` needs for this configuration (0 on error). */
+size_t sttm_quadtree_workspace_bytes(int T, int H, int W, int C, int dtype, int root_level);
+
+/*
+ * Full STTM merge of one video: replaces quadtree_build_video (quadtree_builder.py:85-235) incl.
+ * cross_frame_node_merging_fast (quadtree_temporal_merger.py:271-287).
+ *
+ *   x                     logical [T, C, H, W], element strides (stride_t, stride_c, stride_h, stride_w);
+ *                         stride_c must be 1.  Not written.
+ *   threshold             spatial cosine threshold            (reference arg `threshold`)
+ *   temporal_thresh       <= 0 disables the temporal stage    (reference arg `temporal_thresh`)
+ *   root_level            index into the level-size list, negatives allowed (`root_level`)
+ *   weighted_avg          0/1: sum-pool pyramid + divide by patch count (`weighted_avg`)
+ *   head_dim              0 = whole-vector cosine; > 0 = per-head cosine, mean over heads (`head_dim`)
+ *   workspace             >= sttm_quadtree_workspace_bytes(...) bytes, 256-byte aligned
+ *   feat_out              [T*H*W, C] worst case, dtype of x;  rows [0, N') are valid on return
+ *   npatch_out            [T*H*W] int32
+ *   tlbr_out              [T*H*W, 5] int32 (t, y1, x1, y2, x2)
+ *   counts                int32[STTM_CNT_SLOTS] (device); read counts[STTM_CNT_OUT] after the stream
+ *                         has drained to learn N'.
+ */
+int sttm_quadtree_merge(const void* x, int64_t stride_t, int64_t stride_c, int64_t stride_h, int64_t stride_w,
+                        int T, int C, int H, int W, int dtype,
+                        float threshold, float temporal_thresh, int root_level, int weighted_avg, int head_dim,
+                        void* workspace, size_t workspace_bytes,
+                        void* feat_out, int32_t* npatch_out, int32_t* tlbr_out, int32_t* counts,
+                        void* stream);
+
+/*
+ * Label propagation on an explicit edge list: replaces get_merge_dst_idx_safe
+ * (quadtree_temporal_merger.py:223-269).  pairs is [L, 2] int32 (dst, src); rep_out is [N] int32;
+ * scratch is >= (N + L) * 4 bytes; iters_out (device int32, may be NULL) receives the iteration count.
+ */
+int sttm_merge_dst_idx(const int32_t* pairs, int L, int N, int32_t* rep_out, void* scratch, int32_t* iters_out,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * ToMe baseline: one bipartite_soft_matching + merge_wavg step (tome_token_merger.py:13-91) on a
+ * [n, C] token matrix.  See sttm_tome_workspace_bytes for scratch; outputs hold n - r rows.
+ * ------------------------------------------------------------------------------------------------ */
+size_t sttm_tome_workspace_bytes(int n, int C, int n_head);
+
+/*
+ * Step 1 (matching): for every even token i, best-matching odd token and its cosine score
+ *   node_max[i] = max_j <a_i, b_j>,  node_idx[i] = argmax_j   (first maximum on ties, like torch.max on CPU)
+ * with a = m[0::2], b = m[1::2], m = head-mean of x normalised to unit length (no eps).
+ * node_max: float32[ceil(n/2)], node_idx: int32[ceil(n/2)].
+ */
+int sttm_tome_match(const void* x, int n, int C, int n_head, int dtype, void* workspace, size_t workspace_bytes,
+                    float* node_max, int32_t* node_idx, void* stream);
+
+/*
+ * Step 2 (merge): given the ranking `order` (int64[na], descending node_max, produced by the caller's
+ * stable sort), r, node_idx, sizes and token ids, writes the n - r merged rows:
+ *   [x_a[order[r:]] ... , x_b (+ merged sources, size-weighted average) ...]
+ */
+int sttm_tome_merge(const void* x, const float* size, const int64_t* token_idx, int n, int C, int dtype,
+                    const int64_t* order, int r, const int32_t* node_idx, void* workspace, size_t workspace_bytes,
+                    void* x_out, float* size_out, int64_t* token_idx_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STTM_HIP_H */

@@ -1,0 +1,8 @@
+"""sttm_amd -- MI355X-native STTM token merging (quadtree spatial + temporal merge, ToMe baseline).
+
+Public surface mirrors the reference's `token_merging_utils` boundary:
+    get_quadtree_features, get_tome_features, replace_qwen2_by_sparse_attn
+"""
+from .quadtree_interface import get_quadtree_features  # noqa: F401
+
+__all__ = ["get_quadtree_features"]

@@ -1,0 +1,71 @@
+"""ctypes binding of libsttm_hip.so (the C ABI declared in include/sttm_hip.h).
+
+There is no CPU fallback: if the library is missing or does not load, importing the product path fails
+loudly.  Build it with `python -m sttm_amd.build` (hipcc, gfx950).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsttm_hip.so")
+
+STTM_F32, STTM_BF16, STTM_F16 = 0, 1, 2
+ERR_ARG, ERR_UNSUPPORTED, ERR_LAUNCH, ERR_INDEX, ERR_PARITY = -1, -2, -3, -4, -5
+CNT_NODES, CNT_CANDIDATES, CNT_EDGES, CNT_OUT, CNT_ITERS, CNT_OVERFLOW, CNT_SLOTS = 0, 1, 2, 3, 4, 5, 8
+
+# every symbol include/sttm_hip.h declares, with its ctypes signature
+_vp, _i, _i64, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
+SIGNATURES = {
+    "sttm_abi_version": (_i, []),
+    "sttm_last_error": (ctypes.c_char_p, []),
+    "sttm_quadtree_num_levels": (_i, [_i, _i, _i]),
+    "sttm_quadtree_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "sttm_quadtree_merge": (_i, [_vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _f, _i, _i, _i,
+                                 _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "sttm_merge_dst_idx": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "sttm_tome_workspace_bytes": (_sz, [_i, _i, _i]),
+    "sttm_tome_match": (_i, [_vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp]),
+    "sttm_tome_merge": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises RuntimeError when the HIP library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the STTM HIP extension is not built. Run `python -m sttm_amd.build` "
+            "(needs hipcc; cross-compiles for gfx950 without a GPU). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.sttm_abi_version() != 1:
+        raise RuntimeError("libsttm_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().sttm_last_error().decode("utf-8", "replace")
+
+
+def raise_for(code):
+    """Map a negative return code to the exception type the reference raises in the same situation."""
+    if code >= 0:
+        return
+    msg = last_error()
+    if code == ERR_INDEX:
+        raise IndexError(msg)                 # size_per_level[root_level] (quadtree_builder.py:111)
+    if code == ERR_PARITY:
+        raise RuntimeError(msg)               # sumpool on mixed parity (quadtree_spatial_merger.py:63-84)
+    if code == ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    if code == ERR_ARG:
+        raise ValueError(msg)
+    raise RuntimeError(f"libsttm_hip error {code}: {msg}")

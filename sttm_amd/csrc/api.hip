@@ -1,0 +1,228 @@
+// C-ABI entry points of libsttm_hip.so (declared in include/sttm_hip.h).
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "sttm_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+inline int ceil_half(int v) { return (v + 1) / 2; }
+
+// Level list of quadtree_builder.py:101-117: halve (ceil) until EITHER side is 2, then build pyramid levels
+// until the WIDTH equals the width of entry `root_level` (negative indices count from the fine end).
+int build_dims(int H, int W, int root_level, sttm::LevelDims* out) {
+    if (H < 1 || W < 1 || (H == 1 && W == 1)) return fail(STTM_ERR_ARG, "degenerate token grid %dx%d", H, W);
+    int hs[64], ws[64], n = 1;
+    hs[0] = H; ws[0] = W;                       // fine -> coarse here
+    int h = H, w = W;
+    while (h != 2 && w != 2) {
+        w = ceil_half(w); h = ceil_half(h);
+        if (n >= 63) return fail(STTM_ERR_ARG, "token grid %dx%d never reaches a side of 2", H, W);
+        hs[n] = h; ws[n] = w; ++n;
+    }
+    // python index into the coarse->fine list of length n
+    int idx = root_level < 0 ? root_level + n : root_level;
+    if (idx < 0 || idx >= n) return fail(STTM_ERR_INDEX, "root_level %d out of range for %d levels", root_level, n);
+    const int target_w = ws[n - 1 - idx];
+    int dh[64], dw[64], m = 1;
+    dh[0] = H; dw[0] = W;                       // fine -> coarse
+    while (dw[m - 1] != target_w) {
+        if (m >= 63) return fail(STTM_ERR_ARG, "pyramid never reaches the requested root level");
+        dh[m] = ceil_half(dh[m - 1]); dw[m] = ceil_half(dw[m - 1]); ++m;
+    }
+    if (m > sttm::kMaxLevels)
+        return fail(STTM_ERR_UNSUPPORTED, "%d pyramid levels (grid %dx%d, root_level %d); the device path supports <= %d",
+                    m, H, W, root_level, sttm::kMaxLevels);
+    memset(out, 0, sizeof(*out));
+    out->n_level = m;
+    for (int l = 0; l < m; ++l) { out->h[l] = dh[m - 1 - l]; out->w[l] = dw[m - 1 - l]; }
+    return m;
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline int elem_bytes(int dtype) { return dtype == STTM_F32 ? 4 : 2; }
+
+struct Carve {
+    char* base; size_t off;
+    template <typename P> P* take(size_t bytes) {
+        P* p = reinterpret_cast<P*>(base + off);
+        off = align_up(off + bytes, 256);
+        return p;
+    }
+};
+
+struct Plan {
+    sttm::LevelDims dims;
+    int R, rc_stride, edge_cap, N;
+    size_t bytes;
+};
+
+int make_plan(int T, int H, int W, int C, int dtype, int root_level, Plan* p) {
+    const int D = build_dims(H, W, root_level, &p->dims);
+    if (D < 0) return D;
+    p->R = p->dims.h[0] * p->dims.w[0];
+    p->rc_stride = 1 + sttm::pow4(D - 1);
+    p->N = T * H * W;
+    p->edge_cap = 2 * p->N;
+    Carve c{nullptr, 0};
+    const size_t N = (size_t)p->N;
+    c.take<char>(N * C * elem_bytes(dtype));            // S
+    c.take<char>(N * 4);                                 // meta
+    c.take<char>(N * 4);                                 // nrm2
+    c.take<char>((size_t)T * p->R * p->rc_stride * 4);   // rc_list
+    c.take<char>((size_t)p->edge_cap * 8);               // edges
+    c.take<char>((size_t)p->edge_cap * 4);               // emin
+    for (int i = 0; i < 7; ++i) c.take<char>(N * 4);     // rep rep2 row2origin rank_of grp_cnt grp_cur members
+    c.take<char>((N + 1) * 4);                           // grp_off
+    p->bytes = c.off;
+    return D;
+}
+
+int pick_vec(int C, int dtype, const void* x, int64_t sT, int64_t sH, int64_t sW, int* nt) {
+    const int eb = elem_bytes(dtype);
+    const int cands_f32[] = {4, 2, 1}, cands_16[] = {8, 4, 2};
+    const int* cands = dtype == STTM_F32 ? cands_f32 : cands_16;
+    for (int k = 0; k < 3; ++k) {
+        const int v = cands[k];
+        if (C % v) continue;
+        const size_t ab = (size_t)v * eb;
+        if (reinterpret_cast<uintptr_t>(x) % ab) continue;
+        if ((sT * eb) % ab || (sH * eb) % ab || (sW * eb) % ab) continue;
+        const int lanes = (C + v - 1) / v;
+        if (lanes > 1024) continue;
+        // prefer 16-byte lanes; for 16-bit types a narrower pack halves the VGPRs at equal coalescing
+        // when the whole row still fits one workgroup
+        *nt = ((lanes + 63) / 64) * 64;
+        return v;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sttm_abi_version(void) { return STTM_ABI_VERSION; }
+const char* sttm_last_error(void) { return g_err; }
+
+int sttm_quadtree_num_levels(int H, int W, int root_level) {
+    sttm::LevelDims d;
+    return build_dims(H, W, root_level, &d);
+}
+
+size_t sttm_quadtree_workspace_bytes(int T, int H, int W, int C, int dtype, int root_level) {
+    if (T < 1 || C < 1 || dtype < 0 || dtype > 2) { fail(STTM_ERR_ARG, "bad T/C/dtype"); return 0; }
+    Plan p;
+    if (make_plan(T, H, W, C, dtype, root_level, &p) < 0) return 0;
+    return p.bytes;
+}
+
+int sttm_quadtree_merge(const void* x, int64_t stride_t, int64_t stride_c, int64_t stride_h, int64_t stride_w,
+                        int T, int C, int H, int W, int dtype,
+                        float threshold, float temporal_thresh, int root_level, int weighted_avg, int head_dim,
+                        void* workspace, size_t workspace_bytes,
+                        void* feat_out, int32_t* npatch_out, int32_t* tlbr_out, int32_t* counts,
+                        void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!x || !workspace || !feat_out || !npatch_out || !tlbr_out || !counts) return fail(STTM_ERR_ARG, "null pointer argument");
+    if (T < 1 || C < 1) return fail(STTM_ERR_ARG, "T and C must be positive");
+    if (dtype < 0 || dtype > 2) return fail(STTM_ERR_ARG, "unknown dtype code %d", dtype);
+    if (stride_c != 1) return fail(STTM_ERR_ARG, "channel stride must be 1 (channels-last view); got %lld", (long long)stride_c);
+    if (H > 255 || W > 255) return fail(STTM_ERR_UNSUPPORTED, "token grids larger than 255 per side are not supported");
+    if ((int64_t)T * H * W >= (1ll << 31) / 8) return fail(STTM_ERR_UNSUPPORTED, "too many tokens");
+    if (head_dim != 0) return fail(STTM_ERR_UNSUPPORTED, "per-head similarity (head_dim) is not implemented on the device path yet");
+    Plan p;
+    const int D = make_plan(T, H, W, C, dtype, root_level, &p);
+    if (D < 0) return D;
+    if (workspace_bytes < p.bytes) return fail(STTM_ERR_ARG, "workspace too small: %zu < %zu", workspace_bytes, p.bytes);
+    if (reinterpret_cast<uintptr_t>(workspace) % 256) return fail(STTM_ERR_ARG, "workspace must be 256-byte aligned");
+    if (weighted_avg) {
+        for (int l = 1; l < D; ++l)
+            if ((p.dims.h[l] & 1) != (p.dims.w[l] & 1))
+                return fail(STTM_ERR_PARITY, "weighted_avg needs equal parities at every pooled level; level %dx%d is mixed",
+                            p.dims.h[l], p.dims.w[l]);
+    }
+    int nt = 0;
+    const int vec = pick_vec(C, dtype, x, stride_t, stride_h, stride_w, &nt);
+    if (!vec) return fail(STTM_ERR_UNSUPPORTED, "C=%d with this alignment does not fit one workgroup (need C/vec <= 1024 lanes)", C);
+
+    Carve c{reinterpret_cast<char*>(workspace), 0};
+    const size_t N = (size_t)p.N;
+    sttm::SpatialArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.x = x; sa.sT = stride_t; sa.sH = stride_h; sa.sW = stride_w;
+    sa.T = T; sa.H = H; sa.W = W; sa.C = C;
+    sa.dims = p.dims;
+    sa.threshold = threshold;
+    sa.sum_mode = weighted_avg ? 1 : 0;
+    sa.S = c.take<char>(N * C * elem_bytes(dtype));
+    sa.meta = c.take<uint32_t>(N * 4);
+    sa.nrm2 = c.take<float>(N * 4);
+    sa.rc_list = c.take<int>((size_t)T * p.R * p.rc_stride * 4);
+    sa.rc_stride = p.rc_stride;
+    sa.counts = counts;
+    sa.dbg_sims = nullptr;
+
+    sttm::TemporalArgs ta;
+    memset(&ta, 0, sizeof(ta));
+    ta.T = T; ta.H = H; ta.W = W; ta.C = C; ta.R = p.R;
+    ta.dtype = dtype; ta.vec = vec;
+    ta.temporal_thresh = temporal_thresh;
+    ta.weighted_avg = weighted_avg ? 1 : 0;
+    ta.S = sa.S; ta.meta = sa.meta; ta.nrm2 = sa.nrm2; ta.rc_list = sa.rc_list; ta.rc_stride = p.rc_stride;
+    ta.edges = c.take<int32_t>((size_t)p.edge_cap * 8);
+    ta.edge_cap = p.edge_cap;
+    ta.emin = c.take<int32_t>((size_t)p.edge_cap * 4);
+    ta.rep = c.take<int32_t>(N * 4);
+    ta.rep2 = c.take<int32_t>(N * 4);
+    ta.row2origin = c.take<int32_t>(N * 4);
+    ta.rank_of = c.take<int32_t>(N * 4);
+    ta.grp_cnt = c.take<int32_t>(N * 4);
+    ta.grp_cur = c.take<int32_t>(N * 4);
+    ta.members = c.take<int32_t>(N * 4);
+    ta.grp_off = c.take<int32_t>((N + 1) * 4);
+    ta.counts = counts;
+    ta.feat_out = feat_out; ta.npatch_out = npatch_out; ta.tlbr_out = tlbr_out;
+
+    hipError_t e;
+    if ((e = hipMemsetAsync(counts, 0, sizeof(int32_t) * STTM_CNT_SLOTS, stream)) != hipSuccess ||
+        // grp_cnt and grp_cur are adjacent 256-aligned carves: clear both
+        (e = hipMemsetAsync(ta.grp_cnt, 0, (size_t)((char*)ta.members - (char*)ta.grp_cnt), stream)) != hipSuccess)
+        return fail(STTM_ERR_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+    if ((e = sttm::launch_spatial(sa, dtype, vec, nt, stream)) != hipSuccess)
+        return fail(STTM_ERR_LAUNCH, "spatial kernel: %s", hipGetErrorString(e));
+    if (temporal_thresh > 0.f && T > 1) {
+        if ((e = sttm::launch_pairs(ta, stream)) != hipSuccess)
+            return fail(STTM_ERR_LAUNCH, "pairs kernel: %s", hipGetErrorString(e));
+    }
+    if ((e = sttm::launch_labels(ta, stream)) != hipSuccess)
+        return fail(STTM_ERR_LAUNCH, "labels kernel: %s", hipGetErrorString(e));
+    if ((e = sttm::launch_group_mean(ta, stream)) != hipSuccess)
+        return fail(STTM_ERR_LAUNCH, "group-mean kernel: %s", hipGetErrorString(e));
+    return STTM_OK;
+}
+
+int sttm_merge_dst_idx(const int32_t* pairs, int L, int N, int32_t* rep_out, void* scratch, int32_t* iters_out,
+                       void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (N < 1 || L < 0 || !rep_out || !scratch || (L > 0 && !pairs)) return fail(STTM_ERR_ARG, "bad arguments");
+    int32_t* rep2 = reinterpret_cast<int32_t*>(scratch);
+    int32_t* emin = rep2 + N;
+    hipError_t e = sttm::launch_label_edges(pairs, L, N, rep_out, rep2, emin, iters_out, stream);
+    if (e != hipSuccess) return fail(STTM_ERR_LAUNCH, "label kernel: %s", hipGetErrorString(e));
+    return STTM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,149 @@
+// Shared device/host helpers for the STTM gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sttm {
+
+constexpr int kMaxLevels = 5;   // deepest pyramid the fused spatial kernel supports (root .. leaf)
+constexpr int kWave = 64;
+
+// ---- geometry (closed form of quadtree_spatial_merger.py:155-271 of the reference) -----------------
+// Children of parent index i along one axis when a side of n_child cells is halved:
+//   even: [2i, 2i+1]        odd: i == 0 -> [0]   else [2i-1, 2i]      (first cell stays alone)
+__host__ __device__ __forceinline__ int child_start(int i, int n_child) {
+    return (n_child & 1) ? (i == 0 ? 0 : 2 * i - 1) : 2 * i;
+}
+__host__ __device__ __forceinline__ int child_count(int i, int n_child) {
+    return ((n_child & 1) && i == 0) ? 1 : 2;
+}
+
+struct LevelDims {
+    int n_level;              // pyramid levels built, root level first (index 0), leaf last
+    int h[kMaxLevels + 1];
+    int w[kMaxLevels + 1];
+};
+
+__host__ __device__ __forceinline__ constexpr int pow4(int d) { return 1 << (2 * d); }
+// id of the first node at tree depth d in a complete 4-ary tree stored level by level
+__host__ __device__ __forceinline__ constexpr int depth_base(int d) { return (pow4(d) - 1) / 3; }
+
+// ---- storage packs: VEC consecutive channels of one token, kept in the INPUT dtype -----------------
+struct bf16_t { uint16_t x; };
+struct f16_t { uint16_t x; };
+
+__device__ __forceinline__ float bf16_bits_to_float(uint32_t hi16) { return __uint_as_float(hi16 << 16); }
+__device__ __forceinline__ uint32_t float_to_bf16_bits(float f) {   // round to nearest even, NaN stays NaN
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ float f16_bits_to_float(uint32_t b) {
+    return (float)__builtin_bit_cast(_Float16, (uint16_t)b);
+}
+__device__ __forceinline__ uint32_t float_to_f16_bits(float f) {
+    return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)f);
+}
+
+template <typename T> struct TypeInfo;
+template <> struct TypeInfo<float> { static constexpr int bytes = 4; static constexpr bool lowp = false; };
+template <> struct TypeInfo<bf16_t> { static constexpr int bytes = 2; static constexpr bool lowp = true; };
+template <> struct TypeInfo<f16_t> { static constexpr int bytes = 2; static constexpr bool lowp = true; };
+
+template <typename T, int VEC> struct Pack;
+
+template <int VEC> struct alignas(4 * VEC) Pack<float, VEC> {
+    float v[VEC];
+    __device__ __forceinline__ float get(int i) const { return v[i]; }
+    __device__ __forceinline__ void set(int i, float f) { v[i] = f; }
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) v[i] = 0.f;
+    }
+};
+
+template <typename T16, int VEC> struct alignas(2 * VEC) Pack16 {
+    static_assert(VEC % 2 == 0, "16-bit packs hold an even number of channels");
+    uint32_t w[VEC / 2];
+    __device__ __forceinline__ uint32_t bits(int i) const { return (i & 1) ? (w[i >> 1] >> 16) : (w[i >> 1] & 0xffffu); }
+    __device__ __forceinline__ void set_bits(int i, uint32_t b) {
+        if (i & 1) w[i >> 1] = (w[i >> 1] & 0x0000ffffu) | (b << 16);
+        else w[i >> 1] = (w[i >> 1] & 0xffff0000u) | (b & 0xffffu);
+    }
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < VEC / 2; ++i) w[i] = 0u;
+    }
+};
+template <int VEC> struct Pack<bf16_t, VEC> : Pack16<bf16_t, VEC> {
+    __device__ __forceinline__ float get(int i) const { return bf16_bits_to_float(this->bits(i)); }
+    __device__ __forceinline__ void set(int i, float f) { this->set_bits(i, float_to_bf16_bits(f)); }
+};
+template <int VEC> struct Pack<f16_t, VEC> : Pack16<f16_t, VEC> {
+    __device__ __forceinline__ float get(int i) const { return f16_bits_to_float(this->bits(i)); }
+    __device__ __forceinline__ void set(int i, float f) { this->set_bits(i, float_to_f16_bits(f)); }
+};
+
+template <typename T, int VEC>
+__device__ __forceinline__ Pack<T, VEC> load_pack(const void* base, int64_t elem_off) {
+    return *reinterpret_cast<const Pack<T, VEC>*>(reinterpret_cast<const char*>(base) + elem_off * TypeInfo<T>::bytes);
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void store_pack(void* base, int64_t elem_off, const Pack<T, VEC>& p) {
+    *reinterpret_cast<Pack<T, VEC>*>(reinterpret_cast<char*>(base) + elem_off * TypeInfo<T>::bytes) = p;
+}
+
+template <typename T, int VEC>
+__device__ __forceinline__ float dot_pack(const Pack<T, VEC>& a, const Pack<T, VEC>& b) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s = fmaf(a.get(i), b.get(i), s);
+    return s;
+}
+
+// ---- wave-level reductions -----------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// Butterfly "transpose-reduce": every lane enters with N partial values, and leaves with the full
+// 64-lane total of ONE of them (value index reduce_slot<N>(lane); lanes whose slot is padding get
+// reduce_valid == false).  Costs ~N shuffles instead of 6*N.
+template <int N>
+__device__ __forceinline__ float wave_reduce_many(float (&v)[N], int lane) {
+    static_assert(N >= 1 && N <= 64, "one result per lane");
+    int n = N;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const int half = (n + 1) / 2;
+        const bool up = (lane & m) != 0;
+#pragma unroll
+        for (int i = 0; i < half; ++i) {
+            const float lo = v[i];
+            const float hi = (i + half < n) ? v[i + half] : 0.f;
+            const float keep = up ? hi : lo;
+            const float send = up ? lo : hi;
+            v[i] = keep + __shfl_xor(send, m, 64);
+        }
+        n = half;
+    }
+    return v[0];
+}
+template <int N>
+__device__ __forceinline__ int wave_reduce_slot(int lane, bool& valid) {
+    int n = N, nv = N, idx = 0;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const int half = (n + 1) / 2;
+        if (lane & m) { idx += half; nv = nv - half; if (nv < 0) nv = 0; }
+        else { if (nv > half) nv = half; }
+        n = half;
+    }
+    valid = nv >= 1;
+    return idx;
+}
+
+}  // namespace sttm

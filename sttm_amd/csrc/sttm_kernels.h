@@ -1,0 +1,61 @@
+// Internal kernel-launch interfaces shared by the .hip translation units of libsttm_hip.so.
+#pragma once
+#include "../../include/sttm_hip.h"
+#include "sttm_common.h"
+
+namespace sttm {
+
+struct SpatialArgs {
+    const void* x;            // [T, H, W, C] memory (channels-last view of the logical [T, C, H, W])
+    int64_t sT, sH, sW;       // element strides; the channel stride is 1
+    int T, H, W, C;
+    LevelDims dims;
+    float threshold;
+    int sum_mode;             // weighted_avg: sum-pool pyramid
+    // outputs
+    void* S;                  // [T*H*W, C] node features at their origin rows (input dtype)
+    uint32_t* meta;           // [T*H*W] 0 = no node starts here, else (y2 << 16) | x2
+    float* nrm2;              // [T*H*W] squared L2 norm of the node feature (fp32)
+    int* rc_list;             // [T*R][rc_stride]: count, then packed (y1<<24 | x1<<16 | y2<<8 | x2)
+    int rc_stride;
+    int32_t* counts;          // STTM_CNT_* slots
+    float* dbg_sims;          // optional [T*R][NPAR][4] similarities (debug / tests), may be null
+};
+hipError_t launch_spatial(const SpatialArgs& a, int dtype, int vec, int nt, hipStream_t stream);
+
+struct TemporalArgs {
+    int T, H, W, C, R;        // R = root cells per frame
+    int dtype, vec;
+    float temporal_thresh;    // <= 0: no edges (labels stay the identity)
+    int weighted_avg;
+    const void* S;
+    const uint32_t* meta;
+    const float* nrm2;
+    const int* rc_list;
+    int rc_stride;
+    // scratch
+    int32_t* edges;           // [edge_cap][2] (dst = earlier frame, src = later frame), origin rows
+    int edge_cap;
+    int32_t* emin;            // [edge_cap]
+    int32_t* rep;             // [T*H*W]
+    int32_t* rep2;            // [T*H*W]
+    int32_t* row2origin;      // [T*H*W]
+    int32_t* rank_of;         // [T*H*W]
+    int32_t* grp_cnt;         // [T*H*W]
+    int32_t* grp_cur;         // [T*H*W]
+    int32_t* grp_off;         // [T*H*W + 1]
+    int32_t* members;         // [T*H*W]
+    int32_t* counts;
+    // outputs
+    void* feat_out;
+    int32_t* npatch_out;
+    int32_t* tlbr_out;
+};
+hipError_t launch_pairs(const TemporalArgs& a, hipStream_t stream);
+hipError_t launch_labels(const TemporalArgs& a, hipStream_t stream);
+hipError_t launch_group_mean(const TemporalArgs& a, hipStream_t stream);
+
+hipError_t launch_label_edges(const int32_t* pairs, int L, int N, int32_t* rep_out, int32_t* rep2, int32_t* emin,
+                              int32_t* iters_out, hipStream_t stream);
+
+}  // namespace sttm

@@ -1,0 +1,85 @@
+"""L1 function boundary of STTM, MI355X edition.
+
+`get_quadtree_features` keeps the signature, argument meaning, return types and error behaviour of the
+reference's `token_merging_utils/quadtree_interface.py:5-13` (which forwards to
+`quadtree_builder.py:85-235`), but runs entirely in hand-written HIP kernels behind the C ABI of
+`libsttm_hip.so`.  PyTorch is used for device memory and the current stream only.
+"""
+import torch
+
+from . import _lib
+
+_DTYPE_CODE = {torch.float32: _lib.STTM_F32, torch.bfloat16: _lib.STTM_BF16, torch.float16: _lib.STTM_F16}
+_pinned_counts = {}
+
+
+def _counts_host(device):
+    buf = _pinned_counts.get(device)
+    if buf is None:
+        buf = torch.empty(_lib.CNT_SLOTS, dtype=torch.int32).pin_memory()
+        _pinned_counts[device] = buf
+    return buf
+
+
+def quadtree_merge_raw(x, threshold, temporal_thresh, root_level, weighted_avg, head_dim):
+    """Launch the merge of one video and return the worst-case-sized outputs plus the host counts.
+    x: logical [T, C, H, W] CUDA tensor (any strides; channels-last views run zero-copy)."""
+    if not x.is_cuda:
+        raise RuntimeError("sttm_amd runs on the GPU only: the input must be a CUDA (ROCm) tensor; "
+                           "there is no CPU fallback")
+    if x.dim() != 4:
+        raise ValueError("expected a [T, C, H, W] tensor")
+    if x.dtype not in _DTYPE_CODE:
+        raise NotImplementedError(f"dtype {x.dtype} is not supported (float32, bfloat16, float16)")
+    lib = _lib.load()
+    T, C, H, W = x.shape
+    if x.stride(1) != 1 or (x.data_ptr() % 16) != 0:
+        # not the production (channels-last view) layout: one transposing copy
+        x = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    dev = x.device
+    dtype = _DTYPE_CODE[x.dtype]
+    head_dim = 0 if head_dim is None else int(head_dim)
+    nbytes = lib.sttm_quadtree_workspace_bytes(T, H, W, C, dtype, int(root_level))
+    if nbytes == 0:
+        code = lib.sttm_quadtree_num_levels(H, W, int(root_level))
+        _lib.raise_for(code if code < 0 else _lib.ERR_ARG)
+    N = T * H * W
+    with torch.cuda.device(dev):
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        feat = torch.empty((N, C), dtype=x.dtype, device=dev)
+        npatch = torch.empty(N, dtype=torch.int32, device=dev)
+        tlbr = torch.empty((N, 5), dtype=torch.int32, device=dev)
+        counts = torch.empty(_lib.CNT_SLOTS, dtype=torch.int32, device=dev)
+        stream = torch.cuda.current_stream(dev)
+        rc = lib.sttm_quadtree_merge(
+            x.data_ptr(), x.stride(0), x.stride(1), x.stride(2), x.stride(3), T, C, H, W, dtype,
+            float(threshold), float(temporal_thresh), int(root_level), int(bool(weighted_avg)), head_dim,
+            ws.data_ptr(), nbytes, feat.data_ptr(), npatch.data_ptr(), tlbr.data_ptr(), counts.data_ptr(),
+            stream.cuda_stream)
+        _lib.raise_for(rc)
+        host = _counts_host(dev)
+        host.copy_(counts, non_blocking=True)
+        stream.synchronize()                       # the one unavoidable sync: output sizes are data dependent
+    cnt = host.tolist()
+    if cnt[_lib.CNT_OVERFLOW]:
+        raise RuntimeError("libsttm_hip: internal list overflow (please report): counts=%s" % cnt)
+    return feat, npatch, tlbr, cnt
+
+
+def get_quadtree_features(_video_feature, threshold, temporal_thresh=-1.0, root_level=0, weighted_avg=False,
+                          vis_flag=False, slow_ver=False, head_dim=None, pos_embs=None, pos_emb_weighted_avg=False):
+    """Drop-in for the reference's get_quadtree_features.
+
+    Returns (features [N', C] in the input dtype, num_patches [N'] int32, tlbr [N', 5] int32), all on the
+    input's device; rows are ordered by (t, y1, x1) like the reference's output.
+    """
+    if vis_flag:
+        raise NotImplementedError("vis_flag=True (quadtree_builder_vis) is a plotting aid and is out of scope")
+    if pos_embs is not None:
+        raise NotImplementedError("pos_embs merging (position-embedding ablation) is not implemented yet")
+    if slow_ver and temporal_thresh > 0:
+        raise NotImplementedError("slow_ver=True temporal merging is not implemented on the device path yet")
+    feat, npatch, tlbr, cnt = quadtree_merge_raw(_video_feature, threshold, temporal_thresh, root_level,
+                                                 weighted_avg, head_dim)
+    n = cnt[_lib.CNT_OUT]
+    return feat[:n], npatch[:n], tlbr[:n]

@@ -1,0 +1,72 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every declared symbol, and its host-side
+geometry / argument validation agree with the oracle (no kernel is launched here)."""
+import os
+import re
+
+import pytest
+
+from sttm_amd import _lib
+
+
+def _declared_symbols():
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "sttm_hip.h")
+    text = open(hdr).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sttm_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = _declared_symbols()
+    assert len(names) >= 8
+    for n in names:
+        assert hasattr(lib, n), f"libsttm_hip.so does not export {n}"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
+    assert lib.sttm_abi_version() == 1
+
+
+@pytest.mark.parametrize("H,W", [(14, 14), (27, 27), (20, 36), (18, 26), (13, 24), (16, 22), (10, 30), (7, 7),
+                                  (4, 4), (3, 5), (24, 13), (2, 9), (9, 2), (36, 36)])
+def test_num_levels_matches_oracle_geometry(H, W):
+    from oracle import sttm_oracle as O
+    lib = _lib.load()
+    n = len(O.level_sizes(H, W))
+    for root in range(-n - 1, n + 2):
+        got = lib.sttm_quadtree_num_levels(H, W, root)
+        try:
+            exp = O.Geometry(H, W, root).n_level
+        except IndexError:
+            assert got == _lib.ERR_INDEX
+            continue
+        if exp > 5:
+            assert got == _lib.ERR_UNSUPPORTED
+        else:
+            assert got == exp, (H, W, root)
+
+
+def test_workspace_bytes_and_errors():
+    lib = _lib.load()
+    b = lib.sttm_quadtree_workspace_bytes(128, 14, 14, 1024, _lib.STTM_F32, 1)
+    assert b >= 128 * 196 * 1024 * 4
+    assert lib.sttm_quadtree_workspace_bytes(128, 14, 14, 1024, _lib.STTM_F32, 9) == 0
+    assert "root_level" in _lib.last_error()
+    with pytest.raises(IndexError):
+        _lib.raise_for(_lib.ERR_INDEX)
+    with pytest.raises(NotImplementedError):
+        _lib.raise_for(_lib.ERR_UNSUPPORTED)
+
+
+def test_product_path_has_no_cpu_fallback():
+    import torch
+    from sttm_amd import get_quadtree_features
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        get_quadtree_features(torch.zeros(2, 8, 14, 14), 0.85)
+
+
+def test_product_package_never_imports_the_oracle():
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sttm_amd")
+    for dp, _, files in os.walk(root):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f

