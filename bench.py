@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Benchmark of the STTM merge hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json metric): synth-v1 videos of 128 frames x 14x14 tokens x 1024 channels, fp32, in the
+production layout (channels-last view), full STTM = quadtree spatial merge (thr 0.85, root_level 1) +
+temporal merge (thr 0.55) -- the LLaVA-Video-7B / Video-MME "50 % budget" preset of the reference
+(scripts/eval/run_vidqa.sh:58).  A step = `--videos-per-step` videos through get_quadtree_features, one
+after the other (the reference API is batch-1), inputs resident in HBM, outputs (incl. the host-visible
+token count) produced.  Videos are independent, so N GPUs each take their own videos (weak scaling);
+the only collective is the final all-gather of the per-video token counts over RCCL.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md section "Measurement" for every field).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+KERNELS = ["quadtree_spatial", "temporal_pairs", "labels_scan", "group_mean"]
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--videos-per-step", type=int, default=8)
+    ap.add_argument("--pool", type=int, default=8, help="distinct videos resident per GPU (> L3 capacity in total)")
+    ap.add_argument("--frames", type=int, default=128)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        print(f"[bench] note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from sttm_amd import _lib
+    from sttm_amd.quadtree_interface import get_quadtree_features, quadtree_merge_raw
+    from sttm_amd.synth import synth_video
+    lib = _lib.load()
+
+    T, C, H, W = args.frames, 1024, 14, 14
+    thr, tthr, root = 0.85, 0.55, 1
+    V, P, K, Wm = args.videos_per_step, max(1, args.pool), args.steps, args.warmup
+
+    # ---- inputs: P distinct videos per GPU, generated on the device (same distribution as the CPU stream) ----
+    pool = [synth_video(T, C, H, W, seed=100000 * (rank + 1) + i, device=dev, gen_device=dev) for i in range(P)]
+    torch.cuda.synchronize()
+
+    def run_step(s, sink):
+        for v in range(V):
+            x = pool[(s * V + v) % P]
+            feat, npatch, tlbr = get_quadtree_features(x, thr, tthr, root)
+            sink.append(feat.shape[0])
+
+    def barrier():
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
+
+    sink = []
+    for s in range(Wm):
+        run_step(s, sink)
+    torch.cuda.synchronize()
+    sink = []
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(K):
+        run_step(s, sink)
+    if dist is not None:      # the one exchange step of the job: per-video merged-token counts to every rank
+        mine = torch.tensor(sink, dtype=torch.int32, device=dev)
+        allc = torch.empty(world * mine.numel(), dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(allc, mine)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    videos = world * K * V
+    value = videos / elapsed
+
+    # ---- roofline leg: the same K steps again with HIP events around every kernel of every call ----------
+    lib.sttm_profile_enable(1)
+    ms = (ctypes.c_float * 4)()
+    tot = [0.0] * 4
+    nodes = merged = 0
+    calls = 0
+    for s in range(K):
+        for v in range(V):
+            x = pool[(s * V + v) % P]
+            _, _, _, cnt = quadtree_merge_raw(x, thr, tthr, root, False, None)
+            _lib.raise_for(lib.sttm_profile_last(ms))
+            for i in range(4):
+                tot[i] += ms[i]
+            nodes += cnt[_lib.CNT_NODES]
+            merged += cnt[_lib.CNT_OUT]
+            calls += 1
+    lib.sttm_profile_enable(0)
+    avg_ms = [t / calls for t in tot]
+    n_avg, m_avg = nodes / calls, merged / calls
+    es = 4
+    thw = T * H * W
+    kernel_bytes = [                                     # algorithmic (compulsory) bytes of each kernel per launch
+        es * C * thw + es * C * n_avg + 8 * thw,          # read every token once, write every node once, meta+norm
+        es * C * n_avg,                                   # every node row read once (pairs share rows)
+        4 * thw * 4,                                      # label / scan arrays, once each
+        es * C * n_avg + es * C * m_avg + 24 * m_avg,     # read node rows, write merged rows + tlbr + num_patches
+    ]
+    dom = max(range(4), key=lambda i: avg_ms[i])
+    pipeline_bytes = es * C * thw + es * C * m_avg + 24 * m_avg      # B per video
+    dom_gbs = kernel_bytes[dom] / (avg_ms[dom] * 1e-3) / 1e9
+    pipe_gbs = pipeline_bytes / (sum(avg_ms) * 1e-3) / 1e9
+    traffic = None
+    pmc_path = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_path):
+        try:
+            rec = json.load(open(pmc_path))
+            if rec.get("workload") == f"T{T}_14x14x1024_f32_sttm_0.85_0.55":
+                traffic = rec.get("hbm_bytes_per_launch", {}).get(KERNELS[dom])
+        except Exception:  # noqa: BLE001
+            traffic = None
+    roofline = {
+        "bound": "hbm", "kernel": KERNELS[dom],
+        "achieved": round(dom_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(dom_gbs / HBM_PEAK_GBS, 4),
+        "traffic": traffic,
+        "kernel_ms": {k: round(v, 4) for k, v in zip(KERNELS, avg_ms)},
+        "kernel_algorithmic_MB": {k: round(b / 1e6, 2) for k, b in zip(KERNELS, kernel_bytes)},
+        "pipeline": {"algorithmic_MB_per_video": round(pipeline_bytes / 1e6, 2), "device_ms_per_video": round(sum(avg_ms), 4),
+                     "achieved": round(pipe_gbs, 1), "frac": round(pipe_gbs / HBM_PEAK_GBS, 4)},
+    }
+
+    # ---- CPU baseline leg (rank 0, N = 1 only): the oracle on a bounded sample of the same workload -------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import sttm_oracle as O
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        done, match, spent = 0, 0, 0.0
+        seed = 0
+        xw = synth_video(T, C, H, W, seed=10 ** 6)
+        O.get_quadtree_features(xw, thr, tthr, root)                      # warm-up, untimed
+        while spent < args.cpu_seconds and done < 32:
+            x = synth_video(T, C, H, W, seed=seed)                         # CPU generator: same tensor as tests
+            c0 = time.perf_counter()
+            ef, en, et = O.get_quadtree_features(x, thr, tthr, root)
+            spent += time.perf_counter() - c0
+            f, n, t = get_quadtree_features(x.to(dev), thr, tthr, root)
+            if t.shape == et.shape and torch.equal(t.cpu(), et) and torch.equal(n.cpu(), en):
+                match += 1
+            done += 1
+            seed += 1
+        cpu = {"value": round(done / spent, 3), "unit": "videos/s", "cores": cores, "kind": "port",
+               "sample": f"{done} synth-v1 videos (seeds 0..{done - 1}), T={T} 14x14x1024 fp32, STTM(0.85,0.55,root=1), "
+                         f"oracle/sttm_oracle.py on torch CPU with {cores} threads, after 1 warm-up",
+               "index_exact_videos": match, "videos_checked": done}
+
+    if rank == 0:
+        out = {
+            "metric": "videos/sec (128-frame, 14x14x1024 tokens) STTM merge; merged-index match vs ref",
+            "value": round(value, 2), "unit": "videos/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"synth-v1 T={T} 14x14x1024 fp32, STTM spatial 0.85 + temporal 0.55, root_level 1",
+                       "videos_per_step": V, "pool_per_gpu": P, "global_videos": videos, "parallelism": f"videos sharded x{world}"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        if cpu:
+            out["index_match"] = cpu["index_exact_videos"] / max(1, cpu["videos_checked"])
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -90,6 +90,15 @@ int sttm_quadtree_merge(const void* x, int64_t stride_t, int64_t stride_c, int64
                         void* stream);
 
 /*
+ * Per-kernel timing of sttm_quadtree_merge for the benchmark's roofline leg (not part of the reference API).
+ * While enabled, every call records hipEvents on its stream around its four kernels;
+ * sttm_profile_last waits for the last call and writes milliseconds for
+ * {spatial, pairs, labels, group_mean} into ms_host[4] (HOST memory).
+ */
+int sttm_profile_enable(int on);
+int sttm_profile_last(float* ms_host);
+
+/*
  * Label propagation on an explicit edge list: replaces get_merge_dst_idx_safe
  * (quadtree_temporal_merger.py:223-269).  pairs is [L, 2] int32 (dst, src); rep_out is [N] int32;
  * scratch is >= (N + L) * 4 bytes; iters_out (device int32, may be NULL) receives the iteration count.

@@ -22,6 +22,8 @@ SIGNATURES = {
     "sttm_quadtree_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "sttm_quadtree_merge": (_i, [_vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _f, _i, _i, _i,
                                  _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "sttm_profile_enable": (_i, [_i]),
+    "sttm_profile_last": (_i, [ctypes.POINTER(ctypes.c_float)]),
     "sttm_merge_dst_idx": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "sttm_tome_workspace_bytes": (_sz, [_i, _i, _i]),
     "sttm_tome_match": (_i, [_vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp]),

@@ -10,6 +10,17 @@ namespace {
 
 thread_local char g_err[512] = "";
 
+// Optional per-kernel timing (bench.py's roofline leg): hipEvents recorded on the launch stream around
+// each kernel of sttm_quadtree_merge.  Off by default; costs nothing when off.
+constexpr int kProfSlots = 4;             // spatial, pairs, labels, group_mean
+bool g_prof_on = false;
+hipEvent_t g_prof_ev[kProfSlots + 1];
+bool g_prof_have = false, g_prof_valid = false, g_prof_ran[kProfSlots];
+
+void prof_mark(int i, hipStream_t s) {
+    if (g_prof_on) hipEventRecord(g_prof_ev[i], s);
+}
+
 int fail(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -201,16 +212,48 @@ int sttm_quadtree_merge(const void* x, int64_t stride_t, int64_t stride_c, int64
         // grp_cnt and grp_cur are adjacent 256-aligned carves: clear both
         (e = hipMemsetAsync(ta.grp_cnt, 0, (size_t)((char*)ta.members - (char*)ta.grp_cnt), stream)) != hipSuccess)
         return fail(STTM_ERR_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+    g_prof_valid = false;
+    prof_mark(0, stream);
     if ((e = sttm::launch_spatial(sa, dtype, vec, nt, stream)) != hipSuccess)
         return fail(STTM_ERR_LAUNCH, "spatial kernel: %s", hipGetErrorString(e));
-    if (temporal_thresh > 0.f && T > 1) {
+    prof_mark(1, stream);
+    const bool pairs = temporal_thresh > 0.f && T > 1;
+    if (pairs) {
         if ((e = sttm::launch_pairs(ta, stream)) != hipSuccess)
             return fail(STTM_ERR_LAUNCH, "pairs kernel: %s", hipGetErrorString(e));
     }
+    prof_mark(2, stream);
     if ((e = sttm::launch_labels(ta, stream)) != hipSuccess)
         return fail(STTM_ERR_LAUNCH, "labels kernel: %s", hipGetErrorString(e));
+    prof_mark(3, stream);
     if ((e = sttm::launch_group_mean(ta, stream)) != hipSuccess)
         return fail(STTM_ERR_LAUNCH, "group-mean kernel: %s", hipGetErrorString(e));
+    prof_mark(4, stream);
+    if (g_prof_on) { g_prof_valid = true; g_prof_ran[0] = true; g_prof_ran[1] = pairs; g_prof_ran[2] = true; g_prof_ran[3] = true; }
+    return STTM_OK;
+}
+
+int sttm_profile_enable(int on) {
+    if (on && !g_prof_have) {
+        for (int i = 0; i <= kProfSlots; ++i)
+            if (hipEventCreate(&g_prof_ev[i]) != hipSuccess) return fail(STTM_ERR_LAUNCH, "hipEventCreate failed");
+        g_prof_have = true;
+    }
+    g_prof_on = on != 0;
+    g_prof_valid = false;
+    return STTM_OK;
+}
+
+int sttm_profile_last(float* ms_host) {
+    if (!ms_host) return fail(STTM_ERR_ARG, "null output");
+    if (!g_prof_valid) return fail(STTM_ERR_ARG, "no profiled sttm_quadtree_merge call to report");
+    if (hipEventSynchronize(g_prof_ev[kProfSlots]) != hipSuccess) return fail(STTM_ERR_LAUNCH, "hipEventSynchronize failed");
+    for (int i = 0; i < kProfSlots; ++i) {
+        float ms = 0.f;
+        if (g_prof_ran[i] && hipEventElapsedTime(&ms, g_prof_ev[i], g_prof_ev[i + 1]) != hipSuccess)
+            return fail(STTM_ERR_LAUNCH, "hipEventElapsedTime failed");
+        ms_host[i] = g_prof_ran[i] ? ms : 0.f;
+    }
     return STTM_OK;
 }
 
