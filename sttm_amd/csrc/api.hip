@@ -2,6 +2,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "sttm_kernels.h"
@@ -76,28 +77,68 @@ struct Carve {
 
 struct Plan {
     sttm::LevelDims dims;
-    int R, rc_stride, edge_cap, N;
+    int R, rc_stride, ecap, N, max_slots;
     size_t bytes;
 };
+
+// leaf extent of root cell (I, J): follow first / last children down to the leaf level
+void root_extent_host(const sttm::LevelDims& g, int I, int J, int* ah, int* aw) {
+    int lo_i = I, hi_i = I, lo_j = J, hi_j = J;
+    for (int m = 0; m < g.n_level - 1; ++m) {
+        lo_i = sttm::child_start(lo_i, g.h[m + 1]);
+        hi_i = sttm::child_start(hi_i, g.h[m + 1]) + sttm::child_count(hi_i, g.h[m + 1]) - 1;
+        lo_j = sttm::child_start(lo_j, g.w[m + 1]);
+        hi_j = sttm::child_start(hi_j, g.w[m + 1]) + sttm::child_count(hi_j, g.w[m + 1]) - 1;
+    }
+    *ah = hi_i - lo_i + 1;
+    *aw = hi_j - lo_j + 1;
+}
+
+struct Buffers {
+    char* S; uint32_t* meta; float* nrm2; int* rc_list;
+    int32_t *edges, *edge_cnt, *cand_cnt; unsigned long long* col_mask; int32_t *frame_cnt, *colscratch;
+    int32_t *row2origin, *grp_cnt, *grp_off, *members;
+};
+
+size_t carve_all(const Plan& p, int T, int C, int dtype, char* base, Buffers* b) {
+    Carve c{base, 0};
+    const size_t N = (size_t)p.N;
+    const size_t nfr = (size_t)(T > 1 ? T - 1 : 1) * p.R;
+    Buffers tmp;
+    Buffers& o = b ? *b : tmp;
+    o.S = c.take<char>(N * C * elem_bytes(dtype));
+    o.meta = c.take<uint32_t>(N * 4);
+    o.nrm2 = c.take<float>(N * 4);
+    o.rc_list = c.take<int>((size_t)T * p.R * p.rc_stride * 4);
+    o.edges = c.take<int32_t>(nfr * p.ecap * 8);
+    o.edge_cnt = c.take<int32_t>(nfr * 4);
+    o.cand_cnt = c.take<int32_t>(nfr * 4);
+    o.col_mask = c.take<unsigned long long>((size_t)p.R * 8);
+    o.frame_cnt = c.take<int32_t>((size_t)T * 4);
+    o.colscratch = c.take<int32_t>(N * 16);
+    o.row2origin = c.take<int32_t>(N * 4);
+    o.grp_cnt = c.take<int32_t>(N * 4);
+    o.grp_off = c.take<int32_t>(N * 4);
+    o.members = c.take<int32_t>(N * 4);
+    return c.off;
+}
 
 int make_plan(int T, int H, int W, int C, int dtype, int root_level, Plan* p) {
     const int D = build_dims(H, W, root_level, &p->dims);
     if (D < 0) return D;
     p->R = p->dims.h[0] * p->dims.w[0];
-    p->rc_stride = 1 + sttm::pow4(D - 1);
+    int max_area = 1;
+    for (int I = 0; I < p->dims.h[0]; ++I)
+        for (int J = 0; J < p->dims.w[0]; ++J) {
+            int ah, aw;
+            root_extent_host(p->dims, I, J, &ah, &aw);
+            if (ah * aw > max_area) max_area = ah * aw;
+        }
+    p->rc_stride = 1 + max_area;
+    p->ecap = 2 * max_area;
     p->N = T * H * W;
-    p->edge_cap = 2 * p->N;
-    Carve c{nullptr, 0};
-    const size_t N = (size_t)p->N;
-    c.take<char>(N * C * elem_bytes(dtype));            // S
-    c.take<char>(N * 4);                                 // meta
-    c.take<char>(N * 4);                                 // nrm2
-    c.take<char>((size_t)T * p->R * p->rc_stride * 4);   // rc_list
-    c.take<char>((size_t)p->edge_cap * 8);               // edges
-    c.take<char>((size_t)p->edge_cap * 4);               // emin
-    for (int i = 0; i < 7; ++i) c.take<char>(N * 4);     // rep rep2 row2origin rank_of grp_cnt grp_cur members
-    c.take<char>((N + 1) * 4);                           // grp_off
-    p->bytes = c.off;
+    p->max_slots = T * max_area;
+    p->bytes = carve_all(*p, T, C, dtype, nullptr, nullptr);
     return D;
 }
 
@@ -169,8 +210,10 @@ int sttm_quadtree_merge(const void* x, int64_t stride_t, int64_t stride_c, int64
     const int vec = pick_vec(C, dtype, x, stride_t, stride_h, stride_w, &nt);
     if (!vec) return fail(STTM_ERR_UNSUPPORTED, "C=%d with this alignment does not fit one workgroup (need C/vec <= 1024 lanes)", C);
 
-    Carve c{reinterpret_cast<char*>(workspace), 0};
-    const size_t N = (size_t)p.N;
+    if (p.max_slots > 65536)
+        return fail(STTM_ERR_UNSUPPORTED, "T * (root-cell area) = %d exceeds 65536 label slots per column", p.max_slots);
+    Buffers b;
+    carve_all(p, T, C, dtype, reinterpret_cast<char*>(workspace), &b);
     sttm::SpatialArgs sa;
     memset(&sa, 0, sizeof(sa));
     sa.x = x; sa.sT = stride_t; sa.sH = stride_h; sa.sW = stride_w;
@@ -178,40 +221,32 @@ int sttm_quadtree_merge(const void* x, int64_t stride_t, int64_t stride_c, int64
     sa.dims = p.dims;
     sa.threshold = threshold;
     sa.sum_mode = weighted_avg ? 1 : 0;
-    sa.S = c.take<char>(N * C * elem_bytes(dtype));
-    sa.meta = c.take<uint32_t>(N * 4);
-    sa.nrm2 = c.take<float>(N * 4);
-    sa.rc_list = c.take<int>((size_t)T * p.R * p.rc_stride * 4);
+    sa.S = b.S; sa.meta = b.meta; sa.nrm2 = b.nrm2; sa.rc_list = b.rc_list;
     sa.rc_stride = p.rc_stride;
     sa.counts = counts;
+    sa.frame_cnt = b.frame_cnt;
     sa.dbg_sims = nullptr;
 
     sttm::TemporalArgs ta;
     memset(&ta, 0, sizeof(ta));
     ta.T = T; ta.H = H; ta.W = W; ta.C = C; ta.R = p.R;
+    ta.dims = p.dims;
     ta.dtype = dtype; ta.vec = vec;
     ta.temporal_thresh = temporal_thresh;
     ta.weighted_avg = weighted_avg ? 1 : 0;
-    ta.S = sa.S; ta.meta = sa.meta; ta.nrm2 = sa.nrm2; ta.rc_list = sa.rc_list; ta.rc_stride = p.rc_stride;
-    ta.edges = c.take<int32_t>((size_t)p.edge_cap * 8);
-    ta.edge_cap = p.edge_cap;
-    ta.emin = c.take<int32_t>((size_t)p.edge_cap * 4);
-    ta.rep = c.take<int32_t>(N * 4);
-    ta.rep2 = c.take<int32_t>(N * 4);
-    ta.row2origin = c.take<int32_t>(N * 4);
-    ta.rank_of = c.take<int32_t>(N * 4);
-    ta.grp_cnt = c.take<int32_t>(N * 4);
-    ta.grp_cur = c.take<int32_t>(N * 4);
-    ta.members = c.take<int32_t>(N * 4);
-    ta.grp_off = c.take<int32_t>((N + 1) * 4);
+    ta.max_slots = p.max_slots;
+    {
+        const char* fg = getenv("STTM_FORCE_GMEM_LABELS");
+        ta.force_gmem = (fg && fg[0] == '1') ? 1 : 0;
+    }
+    ta.S = b.S; ta.meta = b.meta; ta.nrm2 = b.nrm2; ta.rc_list = b.rc_list; ta.rc_stride = p.rc_stride;
+    ta.edges = b.edges; ta.ecap = p.ecap; ta.edge_cnt = b.edge_cnt; ta.cand_cnt = b.cand_cnt;
+    ta.col_mask = b.col_mask; ta.frame_cnt = b.frame_cnt; ta.colscratch = b.colscratch;
+    ta.row2origin = b.row2origin; ta.grp_cnt = b.grp_cnt; ta.grp_off = b.grp_off; ta.members = b.members;
     ta.counts = counts;
     ta.feat_out = feat_out; ta.npatch_out = npatch_out; ta.tlbr_out = tlbr_out;
 
     hipError_t e;
-    if ((e = hipMemsetAsync(counts, 0, sizeof(int32_t) * STTM_CNT_SLOTS, stream)) != hipSuccess ||
-        // grp_cnt and grp_cur are adjacent 256-aligned carves: clear both
-        (e = hipMemsetAsync(ta.grp_cnt, 0, (size_t)((char*)ta.members - (char*)ta.grp_cnt), stream)) != hipSuccess)
-        return fail(STTM_ERR_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
     g_prof_valid = false;
     prof_mark(0, stream);
     if ((e = sttm::launch_spatial(sa, dtype, vec, nt, stream)) != hipSuccess)
@@ -223,8 +258,10 @@ int sttm_quadtree_merge(const void* x, int64_t stride_t, int64_t stride_c, int64
             return fail(STTM_ERR_LAUNCH, "pairs kernel: %s", hipGetErrorString(e));
     }
     prof_mark(2, stream);
-    if ((e = sttm::launch_labels(ta, stream)) != hipSuccess)
-        return fail(STTM_ERR_LAUNCH, "labels kernel: %s", hipGetErrorString(e));
+    if ((e = sttm::launch_col_labels(ta, true, stream)) != hipSuccess ||
+        (e = sttm::launch_col_labels(ta, false, stream)) != hipSuccess ||
+        (e = sttm::launch_rank(ta, stream)) != hipSuccess)
+        return fail(STTM_ERR_LAUNCH, "label kernels: %s", hipGetErrorString(e));
     prof_mark(3, stream);
     if ((e = sttm::launch_group_mean(ta, stream)) != hipSuccess)
         return fail(STTM_ERR_LAUNCH, "group-mean kernel: %s", hipGetErrorString(e));

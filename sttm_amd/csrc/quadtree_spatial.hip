@@ -487,8 +487,9 @@ __global__ void __launch_bounds__(MAXNT) k_spatial(SpatialArgs a) {
     __syncthreads();
     if (tid == 0) {
         rc_list[0] = *lcount;
-        atomicAdd(a.counts + STTM_CNT_NODES, *lcount);
+        if (rcell == 0) a.frame_cnt[t] = 0;                  // consumed (atomically) by the label kernels
     }
+    if (blockIdx.x == 0 && tid < STTM_CNT_SLOTS) a.counts[tid] = 0;
 
     // ---- phase 5: store the emitted features ----------------------------------------------------------------
     if constexpr (UL == 0) {

@@ -18,33 +18,37 @@ struct SpatialArgs {
     float* nrm2;              // [T*H*W] squared L2 norm of the node feature (fp32)
     int* rc_list;             // [T*R][rc_stride]: count, then packed (y1<<24 | x1<<16 | y2<<8 | x2)
     int rc_stride;
-    int32_t* counts;          // STTM_CNT_* slots
+    int32_t* counts;          // STTM_CNT_* slots (zeroed here, filled by the later kernels)
+    int32_t* frame_cnt;       // [T] zeroed here for the label kernels
     float* dbg_sims;          // optional [T*R][NPAR][4] similarities (debug / tests), may be null
 };
 hipError_t launch_spatial(const SpatialArgs& a, int dtype, int vec, int nt, hipStream_t stream);
 
 struct TemporalArgs {
     int T, H, W, C, R;        // R = root cells per frame
+    LevelDims dims;
     int dtype, vec;
     float temporal_thresh;    // <= 0: no edges (labels stay the identity)
     int weighted_avg;
+    int max_slots;            // T * (largest root-cell area in leaves)
+    int force_gmem;           // debug/test: run the label kernels on the global-memory path
     const void* S;
     const uint32_t* meta;
     const float* nrm2;
     const int* rc_list;
     int rc_stride;
     // scratch
-    int32_t* edges;           // [edge_cap][2] (dst = earlier frame, src = later frame), origin rows
-    int edge_cap;
-    int32_t* emin;            // [edge_cap]
-    int32_t* rep;             // [T*H*W]
-    int32_t* rep2;            // [T*H*W]
+    int32_t* edges;           // [(T-1)*R][ecap][2] kept edges (dst = earlier frame, src = later frame), origin rows
+    int ecap;
+    int32_t* edge_cnt;        // [(T-1)*R]
+    int32_t* cand_cnt;        // [(T-1)*R]
+    unsigned long long* col_mask;   // [R] per-column idempotency history (bit k = idempotent after iteration k+1)
+    int32_t* frame_cnt;       // [T] survivors per frame (zeroed by the spatial kernel)
+    int32_t* colscratch;      // [4*T*H*W] label arrays of columns that do not fit LDS
     int32_t* row2origin;      // [T*H*W]
-    int32_t* rank_of;         // [T*H*W]
-    int32_t* grp_cnt;         // [T*H*W]
-    int32_t* grp_cur;         // [T*H*W]
-    int32_t* grp_off;         // [T*H*W + 1]
-    int32_t* members;         // [T*H*W]
+    int32_t* grp_cnt;         // [T*H*W] by origin row; 0 = not a survivor
+    int32_t* grp_off;         // [T*H*W] by origin row
+    int32_t* members;         // [T*H*W] origin rows, grouped, ascending inside a group
     int32_t* counts;
     // outputs
     void* feat_out;
@@ -52,8 +56,10 @@ struct TemporalArgs {
     int32_t* tlbr_out;
 };
 hipError_t launch_pairs(const TemporalArgs& a, hipStream_t stream);
-hipError_t launch_labels(const TemporalArgs& a, hipStream_t stream);
+hipError_t launch_col_labels(const TemporalArgs& a, bool probe, hipStream_t stream);
+hipError_t launch_rank(const TemporalArgs& a, hipStream_t stream);
 hipError_t launch_group_mean(const TemporalArgs& a, hipStream_t stream);
+bool col_labels_use_gmem(const TemporalArgs& a);
 
 hipError_t launch_label_edges(const int32_t* pairs, int L, int N, int32_t* rep_out, int32_t* rep2, int32_t* emin,
                               int32_t* iters_out, hipStream_t stream);

@@ -1,17 +1,24 @@
 // K2..K5 -- temporal stage of STTM on gfx950.
 //
-//   k_pairs       candidate pairs + cosine filter   (quadtree_temporal_merger.py:8-73 of the reference)
-//   k_labels      synchronous hook + pointer-jump label propagation, survivor scan, group lists
-//                                                   (:223-269 and the bookkeeping half of :123-171)
-//   k_group_mean  per-survivor ascending-order accumulation and mean                 (:123-171)
+//   k_pairs        candidate pairs + cosine filter            (quadtree_temporal_merger.py:8-73 of the reference)
+//   k_col_labels   label propagation per root-cell column, in LDS                              (:223-269)
+//                  <PROBE>: records after which iterations the column is idempotent
+//                  <FINAL>: replays exactly the global iteration count, then builds survivors + group lists
+//   k_rank         output row of every survivor (prefix sum in origin order)      (bookkeeping of :134-140)
+//   k_group_mean   per-survivor ascending-order accumulation and mean                           (:123-171)
 //
-// All of them address nodes by their ORIGIN ROW  t*H*W + y1*W + x1  in the scratch matrix S written by
-// the spatial kernel.  Origin rows are ordered exactly like the reference's sorted node indices, so
-// min-label propagation over origin rows is the same computation as over node indices.
+// All of them address nodes by their ORIGIN ROW  t*H*W + y1*W + x1  in the scratch matrix S written by the
+// spatial kernel.  Origin rows are ordered exactly like the reference's sorted node indices, so min-label
+// propagation over origin rows is the same computation as over node indices.
 //
-// Candidate pairs never cross root cells (a node lies inside exactly one root cell and root cells are the
-// same in every frame), so one workgroup per (frame pair, root cell) enumerates <= 16x16 box tests instead
-// of the reference's dense [T-1, M, M, 4] tensor.
+// Structure that makes this cheap: a node lies inside exactly one root cell and root cells are the same in
+// every frame, so (a) candidate pairs never cross root cells -- one workgroup per (frame pair, root cell)
+// enumerates <= 16x16 box tests instead of the reference's dense [T-1, M, M, 4] tensor -- and (b) the label
+// graph splits into R independent columns (one per root cell, T frames deep) that fit in LDS.  The reference's
+// loop is synchronous and stops at the first iteration where ALL labels are idempotent (quirk Q2: that is not
+// connected components), so the columns must all run the same number of iterations: the PROBE pass reports
+// each column's per-iteration idempotency, the FINAL pass derives the global count K from all reports and
+// replays exactly K iterations.  No grid barrier, no co-residency assumption, no same-address atomics.
 #include "sttm_kernels.h"
 
 namespace sttm {
@@ -24,22 +31,25 @@ __device__ __forceinline__ void st_agent(int32_t* p, int v) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K2: pairs
+// K2: pairs.  One workgroup per (t, root cell): box tests between the node lists of frames t and t+1,
+// then one wave per candidate for the C-long dot product (two candidates in flight per wave).
+// Kept edges go to this workgroup's own slot list -- no global counters.
 // ---------------------------------------------------------------------------------------------------
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256) k_pairs(TemporalArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    int* cand = reinterpret_cast<int*>(smem_raw);     // [2 * cap] (index into A list, index into B list)
-    __shared__ int ncand;
+    int* cand = reinterpret_cast<int*>(smem_raw);     // [cap] packed (ia << 16 | ib)
+    __shared__ int ncand, nkept;
     const int R = a.R;
     const int t = blockIdx.x / R, r = blockIdx.x % R;
     const int HW = a.H * a.W;
     const int* LA = a.rc_list + (int64_t)(t * R + r) * a.rc_stride;
     const int* LB = a.rc_list + (int64_t)((t + 1) * R + r) * a.rc_stride;
     const int nA = LA[0], nB = LB[0];
-    const int cap = 2 * (a.rc_stride - 1);
+    const int cap = a.ecap;
+    int32_t* my_edges = a.edges + (int64_t)blockIdx.x * cap * 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
-    if (tid == 0) ncand = 0;
+    if (tid == 0) { ncand = 0; nkept = 0; }
     __syncthreads();
     for (int p = tid; p < nA * nB; p += blockDim.x) {
         const int ia = p / nB, ib = p - ia * nB;
@@ -50,44 +60,57 @@ __global__ void __launch_bounds__(256) k_pairs(TemporalArgs a) {
         const bool b_has_a = ay1 >= by1 && ax1 >= bx1 && ay2 <= by2 && ax2 <= bx2;
         if (a_has_b || b_has_a) {
             const int pos = atomicAdd(&ncand, 1);
-            if (pos < cap) { cand[2 * pos] = ia; cand[2 * pos + 1] = ib; }
+            if (pos < cap) cand[pos] = (ia << 16) | ib;
         }
     }
     __syncthreads();
     const int nc = ncand < cap ? ncand : cap;
-    if (tid == 0) {
-        atomicAdd(a.counts + STTM_CNT_CANDIDATES, ncand);
-        if (ncand > cap) atomicAdd(a.counts + STTM_CNT_OVERFLOW, 1);
-    }
-    for (int c = wave; c < nc; c += nwave) {
-        const unsigned ba = (unsigned)LA[1 + cand[2 * c]], bb = (unsigned)LB[1 + cand[2 * c + 1]];
-        const int rowA = t * HW + (int)(ba >> 24) * a.W + (int)((ba >> 16) & 255);
-        const int rowB = (t + 1) * HW + (int)(bb >> 24) * a.W + (int)((bb >> 16) & 255);
-        float dot = 0.f;
+    auto row_of = [&](const int* L, int i, int frame) {
+        const unsigned b = (unsigned)L[1 + i];
+        return frame * HW + (int)(b >> 24) * a.W + (int)((b >> 16) & 255);
+    };
+    for (int c = wave; c < nc; c += 2 * nwave) {
+        const int c2 = c + nwave;
+        const bool two = c2 < nc;
+        const int k0 = cand[c], k1 = two ? cand[c2] : k0;
+        const int rowA0 = row_of(LA, k0 >> 16, t), rowB0 = row_of(LB, k0 & 0xffff, t + 1);
+        const int rowA1 = row_of(LA, k1 >> 16, t), rowB1 = row_of(LB, k1 & 0xffff, t + 1);
+        float d0 = 0.f, d1 = 0.f;
         for (int c0 = lane * VEC; c0 < a.C; c0 += 64 * VEC) {
-            const Pack<T, VEC> pa = load_pack<T, VEC>(a.S, (int64_t)rowA * a.C + c0);
-            const Pack<T, VEC> pb = load_pack<T, VEC>(a.S, (int64_t)rowB * a.C + c0);
-            dot += dot_pack(pa, pb);
+            const Pack<T, VEC> pa0 = load_pack<T, VEC>(a.S, (int64_t)rowA0 * a.C + c0);
+            const Pack<T, VEC> pb0 = load_pack<T, VEC>(a.S, (int64_t)rowB0 * a.C + c0);
+            const Pack<T, VEC> pa1 = load_pack<T, VEC>(a.S, (int64_t)rowA1 * a.C + c0);
+            const Pack<T, VEC> pb1 = load_pack<T, VEC>(a.S, (int64_t)rowB1 * a.C + c0);
+            d0 += dot_pack(pa0, pb0);
+            d1 += dot_pack(pa1, pb1);
         }
-        dot = wave_sum(dot);
-        if (lane == 0) {
+        d0 = wave_sum(d0);
+        d1 = wave_sum(d1);
+        if (lane < 2 && (lane == 0 || two)) {
+            const int rowA = lane ? rowA1 : rowA0, rowB = lane ? rowB1 : rowB0;
+            const float dot = lane ? d1 : d0;
             // x / (|x| + 1e-8) on both sides (quadtree_temporal_merger.py:62-63), evaluated in double
             const double na = sqrt((double)a.nrm2[rowA]) + 1e-8;
             const double nb = sqrt((double)a.nrm2[rowB]) + 1e-8;
             const float sim = (float)((double)dot / (na * nb));
             if (sim >= a.temporal_thresh) {
-                const int e = atomicAdd(a.counts + STTM_CNT_EDGES, 1);
-                if (e < a.edge_cap) { a.edges[2 * e] = rowA; a.edges[2 * e + 1] = rowB; }
-                else atomicAdd(a.counts + STTM_CNT_OVERFLOW, 1);
+                const int e = atomicAdd(&nkept, 1);
+                my_edges[2 * e] = rowA;
+                my_edges[2 * e + 1] = rowB;
             }
         }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        a.edge_cnt[blockIdx.x] = nkept;
+        a.cand_cnt[blockIdx.x] = ncand;
     }
 }
 
 hipError_t launch_pairs(const TemporalArgs& a, hipStream_t stream) {
     if (a.T < 2) return hipSuccess;
     const int grid = (a.T - 1) * a.R;
-    const size_t smem = sizeof(int) * 4 * (size_t)(a.rc_stride - 1);
+    const size_t smem = sizeof(int) * (size_t)a.ecap;
 #define STTM_LAUNCH_PAIRS(TT, VV) hipLaunchKernelGGL((k_pairs<TT, VV>), dim3(grid), dim3(256), smem, stream, a)
     if (a.dtype == STTM_F32) {
         if (a.vec == 4) STTM_LAUNCH_PAIRS(float, 4); else if (a.vec == 2) STTM_LAUNCH_PAIRS(float, 2); else STTM_LAUNCH_PAIRS(float, 1);
@@ -101,12 +124,8 @@ hipError_t launch_pairs(const TemporalArgs& a, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K3: labels (single workgroup).  Every access to the label arrays is an agent-scope (L2-served)
-// load/store/atomic, so phases separated by __syncthreads() see each other's writes without L1 games.
-// ---------------------------------------------------------------------------------------------------
-constexpr int kLabelThreads = 1024;
-
 // Block-wide exclusive scan of one int per thread; returns the exclusive prefix, *total gets the sum.
+// ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int block_exclusive_scan(int v, int* lds_wave /*[16]*/, int* total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     int inc = v;
@@ -128,66 +147,45 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* lds_wave /*[16]*
     return base + inc - v;
 }
 
-// The synchronous iteration of get_merge_dst_idx_safe.  `cur`/`nxt` ping-pong; returns the buffer that
-// holds the converged labels.  All threads of the (single) workgroup call it.
-__device__ int32_t* propagate_labels(const int32_t* edges, int L, int N, int32_t* cur, int32_t* nxt, int32_t* emin,
-                                     int* lds_flag, int* iters_out) {
-    const int tid = threadIdx.x, nt = blockDim.x;
-    int iters = 0;
-    while (true) {
-        // m_e = min(rep[d_e], rep[s_e]) for every edge, all from the OLD labels
-        for (int e = tid; e < L; e += nt) {
-            const int d = edges[2 * e], s = edges[2 * e + 1];
-            const int rd = ld_agent(cur + d), rs = ld_agent(cur + s);
-            emin[e] = rd < rs ? rd : rs;
-        }
-        if (tid == 0) *lds_flag = 0;
-        __syncthreads();
-        // scatter-amin on both endpoints
-        for (int e = tid; e < L; e += nt) {
-            const int m = emin[e];
-            __hip_atomic_fetch_min(cur + edges[2 * e], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_min(cur + edges[2 * e + 1], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-        // pointer jump: nxt = cur[cur]
-        for (int i = tid; i < N; i += nt) st_agent(nxt + i, ld_agent(cur + ld_agent(cur + i)));
-        __syncthreads();
-        // converged when nxt == nxt[nxt]
-        int bad = 0;
-        for (int i = tid; i < N; i += nt) {
-            const int v = ld_agent(nxt + i);
-            if (ld_agent(nxt + v) != v) bad = 1;
-        }
-        if (bad) *lds_flag = 1;
-        __syncthreads();
-        const int again = *lds_flag;
-        __syncthreads();
-        int32_t* tmp = cur; cur = nxt; nxt = tmp;
-        ++iters;
-        if (!again) break;
+// ---------------------------------------------------------------------------------------------------
+// K3: column labels.
+// A column = root cell (I, J) over all T frames.  Local slot of leaf (t, y, x) inside the column:
+//   s = t*A + (y - Y1)*aw + (x - X1),   A = area of the root cell in leaves; monotone in the origin row.
+// ---------------------------------------------------------------------------------------------------
+struct Column {
+    int Y1, X1, ah, aw, A, slots, base;   // base = T * (leaves of the root cells before this one)
+};
+__device__ __forceinline__ void root_extent(const LevelDims& g, int I, int J, int& y1, int& y2, int& x1, int& x2) {
+    int lo_i = I, hi_i = I, lo_j = J, hi_j = J;
+    for (int m = 0; m < g.n_level - 1; ++m) {
+        lo_i = child_start(lo_i, g.h[m + 1]);
+        hi_i = child_start(hi_i, g.h[m + 1]) + child_count(hi_i, g.h[m + 1]) - 1;
+        lo_j = child_start(lo_j, g.w[m + 1]);
+        hi_j = child_start(hi_j, g.w[m + 1]) + child_count(hi_j, g.w[m + 1]) - 1;
     }
-    *iters_out = iters;
-    return cur;
+    y1 = lo_i; y2 = hi_i + 1; x1 = lo_j; x2 = hi_j + 1;
 }
-
-__global__ void __launch_bounds__(kLabelThreads) k_label_edges(const int32_t* pairs, int L, int N, int32_t* rep_out,
-                                                               int32_t* rep2, int32_t* emin, int32_t* iters_out) {
-    __shared__ int flag;
-    for (int i = threadIdx.x; i < N; i += blockDim.x) st_agent(rep_out + i, i);
-    __syncthreads();
-    int iters = 0;
-    int32_t* fin = propagate_labels(pairs, L, N, rep_out, rep2, emin, &flag, &iters);
-    if (fin != rep_out) {
-        for (int i = threadIdx.x; i < N; i += blockDim.x) st_agent(rep_out + i, ld_agent(fin + i));
-    }
-    if (threadIdx.x == 0 && iters_out) *iters_out = iters;
+__device__ __forceinline__ Column make_column(const TemporalArgs& a, int r) {
+    const LevelDims& g = a.dims;
+    const int I = r / g.w[0], J = r % g.w[0];
+    int y1, y2, x1, x2;
+    root_extent(g, I, J, y1, y2, x1, x2);
+    Column c;
+    c.Y1 = y1; c.X1 = x1; c.ah = y2 - y1; c.aw = x2 - x1; c.A = c.ah * c.aw; c.slots = a.T * c.A;
+    // leaves owned by root cells 0..r-1: full root rows above + cells to the left in this root row
+    c.base = a.T * (y1 * a.W + (y2 - y1) * x1);
+    return c;
 }
-
-hipError_t launch_label_edges(const int32_t* pairs, int L, int N, int32_t* rep_out, int32_t* rep2, int32_t* emin,
-                              int32_t* iters_out, hipStream_t stream) {
-    hipLaunchKernelGGL(k_label_edges, dim3(1), dim3(kLabelThreads), 0, stream, pairs, L, N, rep_out, rep2, emin, iters_out);
-    return hipGetLastError();
+__device__ __forceinline__ int slot_to_row(const TemporalArgs& a, const Column& c, int s) {
+    const int t = s / c.A, q = s - t * c.A;
+    const int ly = q / c.aw, lx = q - ly * c.aw;
+    return t * a.H * a.W + (c.Y1 + ly) * a.W + (c.X1 + lx);
+}
+__device__ __forceinline__ int row_to_slot(const TemporalArgs& a, const Column& c, int row) {
+    const int HW = a.H * a.W;
+    const int t = row / HW, rem = row - t * HW;
+    const int y = rem / a.W, x = rem - y * a.W;
+    return t * c.A + (y - c.Y1) * c.aw + (x - c.X1);
 }
 
 __device__ __forceinline__ int box_area(uint32_t meta, int row, int HW, int W) {
@@ -197,93 +195,342 @@ __device__ __forceinline__ int box_area(uint32_t meta, int row, int HW, int W) {
     return (y2 - y1) * (x2 - x1);
 }
 
-__global__ void __launch_bounds__(kLabelThreads) k_labels(TemporalArgs a) {
-    __shared__ int flag;
-    __shared__ int wsum[16];
+constexpr int kColThreads = 1024;
+constexpr int kMaxProbeIters = 62;
+
+// Column arrays live in LDS (GMEM == false) or, for columns too large for the 160 KB LDS, in a per-column
+// slice of global scratch (GMEM == true).  In global memory every access is agent scope (L2-served), so
+// phases separated by __syncthreads() see each other's plain writes and atomics alike.
+template <bool GMEM> __device__ __forceinline__ int cld(const int* p) {
+    if constexpr (GMEM) return ld_agent(p); else return *p;
+}
+template <bool GMEM> __device__ __forceinline__ void cst(int* p, int v) {
+    if constexpr (GMEM) st_agent(p, v); else *p = v;
+}
+template <bool GMEM> __device__ __forceinline__ void camin(int* p, int v) {
+    if constexpr (GMEM) __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else atomicMin(p, v);
+}
+template <bool GMEM> __device__ __forceinline__ int caadd(int* p, int v) {
+    if constexpr (GMEM) return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return atomicAdd(p, v);
+}
+
+// One synchronous iteration of get_merge_dst_idx_safe.
+//   rep  : labels before (read only during the edge pass)       rep2 : copy of rep that receives the amin scatter
+// after the call rep == rep2 == new labels.  flags[0] = some label changed, flags[1] = not idempotent.
+template <bool GMEM>
+__device__ __forceinline__ void column_iteration(int* rep, int* rep2, const int* edges, int E, int slots, int* flags) {
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int N = a.T * a.H * a.W;
-    int32_t* rep = a.rep;
-    for (int i = tid; i < N; i += nt) st_agent(a.rep + i, i);
-    __syncthreads();
-    int L = 0;
-    if (a.temporal_thresh > 0.f) {
-        L = ld_agent(a.counts + STTM_CNT_EDGES);
-        if (L > a.edge_cap) L = a.edge_cap;
-    }
-    int32_t* spare = a.rep2;
-    if (L > 0) {
-        int iters = 0;
-        rep = propagate_labels(a.edges, L, N, a.rep, a.rep2, a.emin, &flag, &iters);
-        spare = (rep == a.rep) ? a.rep2 : a.rep;
-        if (tid == 0) a.counts[STTM_CNT_ITERS] = iters;
-    }
-    // ---- survivors: nodes that are their own representative, ranked in origin-row order -----------------
-    const int per = (N + nt - 1) / nt;
-    const int lo = tid * per < N ? tid * per : N;
-    const int hi = lo + per < N ? lo + per : N;
-    int mine = 0;
-    for (int i = lo; i < hi; ++i) mine += (a.meta[i] != 0u && ld_agent(rep + i) == i) ? 1 : 0;
-    int n_out = 0;
-    int base = block_exclusive_scan(mine, wsum, &n_out);
-    for (int i = lo; i < hi; ++i) {
-        if (a.meta[i] != 0u && ld_agent(rep + i) == i) {
-            st_agent(a.row2origin + base, i);
-            st_agent(a.rank_of + i, base);
-            ++base;
-        }
-    }
-    if (tid == 0) a.counts[STTM_CNT_OUT] = n_out;
-    __syncthreads();
-    // ---- group sizes (grp_cnt / grp_cur were zeroed by the host-side memset) -----------------------------
-    for (int i = tid; i < N; i += nt) {
-        if (a.meta[i] != 0u) {
-            const int g = ld_agent(a.rank_of + ld_agent(rep + i));
-            __hip_atomic_fetch_add(a.grp_cnt + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+    if (tid == 0) { flags[0] = 0; flags[1] = 0; }
+    for (int e = tid; e < E; e += nt) {
+        const unsigned pr = (unsigned)cld<GMEM>(edges + e);
+        const int d = pr >> 16, s = pr & 0xffffu;
+        const int rd = cld<GMEM>(rep + d), rs = cld<GMEM>(rep + s);
+        const int m = rd < rs ? rd : rs;
+        camin<GMEM>(rep2 + d, m);
+        camin<GMEM>(rep2 + s, m);
     }
     __syncthreads();
-    // ---- offsets: exclusive scan of grp_cnt[0 .. n_out) ----------------------------------------------------
-    const int per2 = (n_out + nt - 1) / nt;
-    const int lo2 = tid * per2 < n_out ? tid * per2 : n_out;
-    const int hi2 = lo2 + per2 < n_out ? lo2 + per2 : n_out;
-    int sum2 = 0;
-    for (int g = lo2; g < hi2; ++g) sum2 += ld_agent(a.grp_cnt + g);
-    int tot2 = 0;
-    int off = block_exclusive_scan(sum2, wsum, &tot2);
-    for (int g = lo2; g < hi2; ++g) {
-        st_agent(a.grp_off + g, off);
-        off += ld_agent(a.grp_cnt + g);
+    int changed = 0;
+    for (int i = tid; i < slots; i += nt) {
+        const int v = cld<GMEM>(rep2 + cld<GMEM>(rep2 + i));
+        if (v != cld<GMEM>(rep + i)) changed = 1;
+        cst<GMEM>(rep + i, v);
     }
-    if (tid == 0) st_agent(a.grp_off + n_out, tot2);
+    if (changed) flags[0] = 1;
     __syncthreads();
-    // ---- fill (unordered), then order every multi-member group ascending -------------------------------------
-    for (int i = tid; i < N; i += nt) {
-        if (a.meta[i] != 0u) {
-            const int g = ld_agent(a.rank_of + ld_agent(rep + i));
-            const int pos = ld_agent(a.grp_off + g) +
-                            __hip_atomic_fetch_add(a.grp_cur + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            st_agent(spare + pos, i);
-        }
+    int bad = 0;
+    for (int i = tid; i < slots; i += nt) {
+        const int v = cld<GMEM>(rep + i);
+        cst<GMEM>(rep2 + i, v);
+        if (cld<GMEM>(rep + v) != v) bad = 1;
     }
+    if (bad) flags[1] = 1;
     __syncthreads();
+}
+
+template <bool FINAL, bool GMEM>
+__global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __shared__ int flags[2];
+    __shared__ int wsum[16];
+    __shared__ unsigned long long wmask[16];
+    const int r = blockIdx.x, R = a.R;
+    const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nwave = nt >> 6;
-    for (int g = wave; g < n_out; g += nwave) {
-        const int o = ld_agent(a.grp_off + g), n = ld_agent(a.grp_cnt + g);
-        if (n == 1) {
-            if (lane == 0) st_agent(a.members + o, ld_agent(spare + o));
-            continue;
+    const Column col = make_column(a, r);
+    const int slots = col.slots;
+    // four arrays of `slots` ints each
+    int* A0 = GMEM ? a.colscratch + (int64_t)4 * col.base : reinterpret_cast<int*>(smem_raw);
+    int* rep = A0;                 // labels
+    int* rep2 = A0 + slots;        // scatter target during iterations; group sizes afterwards
+    int* edges = A0 + 2 * slots;   // [E] packed local (dst << 16 | src) during iterations (E <= 2 * slots)
+    int* aux = A0 + 2 * slots;     // afterwards: group offsets / fill cursor
+    int* mem = A0 + 3 * slots;     // afterwards: unordered member lists
+    const bool temporal = a.temporal_thresh > 0.f && a.T > 1;
+
+    // ---- gather this column's edges (local slot ids) ------------------------------------------------------
+    int E = 0;
+    if (temporal) {
+        const int nf = a.T - 1;
+        const int per = (nf + nt - 1) / nt;
+        const int lo = tid * per < nf ? tid * per : nf, hi = lo + per < nf ? lo + per : nf;
+        int mine = 0;
+        for (int t = lo; t < hi; ++t) mine += a.edge_cnt[t * R + r];
+        int off = block_exclusive_scan(mine, wsum, &E);
+        for (int t = lo; t < hi; ++t) {
+            const int n = a.edge_cnt[t * R + r];
+            const int32_t* src = a.edges + (int64_t)(t * R + r) * a.ecap * 2;
+            for (int k = 0; k < n; ++k) {
+                const unsigned d = (unsigned)row_to_slot(a, col, src[2 * k]), sl = (unsigned)row_to_slot(a, col, src[2 * k + 1]);
+                cst<GMEM>(edges + off + k, (int)((d << 16) | sl));
+            }
+            off += n;
         }
-        for (int m = lane; m < n; m += 64) {
-            const int v = ld_agent(spare + o + m);
-            int rk = 0;
-            for (int j = 0; j < n; ++j) rk += ld_agent(spare + o + j) < v ? 1 : 0;
-            st_agent(a.members + o + rk, v);
+    }
+    for (int i = tid; i < slots; i += nt) { cst<GMEM>(rep + i, i); cst<GMEM>(rep2 + i, i); }
+    __syncthreads();
+
+    if constexpr (!FINAL) {
+        // ---- PROBE: iterate to the fixed point, remember after which iterations the labels were idempotent --
+        unsigned long long mask = 0ull;
+        int it = 0;
+        bool overflow = false;
+        while (true) {
+            column_iteration<GMEM>(rep, rep2, edges, E, slots, flags);
+            const int changed = flags[0], bad = flags[1];
+            __syncthreads();
+            if (!bad) mask |= 1ull << it;
+            ++it;
+            if (!changed) break;                 // fixed point: stable => idempotent from here on
+            if (it >= kMaxProbeIters) { overflow = true; break; }
+        }
+        if (tid == 0) {
+            mask |= ~0ull << (it - 1);           // the labels no longer move: every later iteration is idempotent
+            a.col_mask[r] = mask;
+            if (overflow) atomicAdd(a.counts + STTM_CNT_OVERFLOW, 1);
+        }
+        return;
+    } else {
+        // ---- FINAL: K = first iteration after which EVERY column is idempotent; replay exactly K iterations --
+        int K = 0;
+        if (temporal) {
+            unsigned long long m = ~0ull;
+            for (int c = tid; c < R; c += nt) m &= a.col_mask[c];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) m &= __shfl_xor(m, d, 64);
+            if (lane == 0) wmask[wave] = m;
+            __syncthreads();
+            unsigned long long all = ~0ull;
+            for (int w = 0; w < nwave; ++w) all &= wmask[w];
+            K = all ? __ffsll((long long)all) : kMaxProbeIters;      // lowest set bit index + 1
+            for (int it = 0; it < K; ++it) column_iteration<GMEM>(rep, rep2, edges, E, slots, flags);
+        }
+        // from here: rep = final labels; rep2, the edge array and `mem` are free
+        int* gcnt = rep2;
+        for (int i = tid; i < slots; i += nt) cst<GMEM>(gcnt + i, 0);
+        __syncthreads();
+        int nodes = 0;
+        for (int i = tid; i < slots; i += nt) {
+            if (a.meta[slot_to_row(a, col, i)] != 0u) { caadd<GMEM>(gcnt + cld<GMEM>(rep + i), 1); ++nodes; }
+        }
+        __syncthreads();
+        // offsets of the groups inside this column's slice of `members` (exclusive scan over slots)
+        {
+            const int per = (slots + nt - 1) / nt;
+            const int lo = tid * per < slots ? tid * per : slots, hi = lo + per < slots ? lo + per : slots;
+            int mine = 0;
+            for (int i = lo; i < hi; ++i) mine += cld<GMEM>(gcnt + i);
+            int tot = 0;
+            int off = block_exclusive_scan(mine, wsum, &tot);
+            for (int i = lo; i < hi; ++i) {
+                const int n = cld<GMEM>(gcnt + i);
+                cst<GMEM>(aux + i, off);
+                const int row = slot_to_row(a, col, i);
+                a.grp_off[row] = col.base + off;
+                a.grp_cnt[row] = n;                   // 0 for non-survivors: k_rank keys on this
+                off += n;
+            }
+        }
+        __syncthreads();
+        // survivors per frame -> frame_cnt (one atomic per (frame, column))
+        if (col.A <= 64) {
+            for (int t = tid; t < a.T; t += nt) {
+                int c = 0;
+                for (int q = 0; q < col.A; ++q) c += cld<GMEM>(gcnt + t * col.A + q) > 0 ? 1 : 0;
+                if (c) atomicAdd(a.frame_cnt + t, c);
+            }
+        } else {
+            for (int t = wave; t < a.T; t += nwave) {
+                int c = 0;
+                for (int q = lane; q < col.A; q += 64) c += cld<GMEM>(gcnt + t * col.A + q) > 0 ? 1 : 0;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+                if (lane == 0 && c) atomicAdd(a.frame_cnt + t, c);
+            }
+        }
+        // unordered fill (cursor = aux), then order every multi-member group ascending and publish global rows
+        for (int i = tid; i < slots; i += nt) {
+            if (a.meta[slot_to_row(a, col, i)] != 0u) {
+                const int pos = caadd<GMEM>(aux + cld<GMEM>(rep + i), 1);
+                cst<GMEM>(mem + pos, i);
+            }
+        }
+        __syncthreads();
+        int32_t* out = a.members + col.base;
+        // small groups (the common case): one thread ranks its own group; big ones are left to whole waves
+        constexpr int kSmall = 24;
+        if (tid == 0) flags[0] = 0;
+        __syncthreads();
+        for (int i = tid; i < slots; i += nt) {
+            const int n = cld<GMEM>(gcnt + i);
+            if (n == 0) continue;
+            const int o = cld<GMEM>(aux + i) - n;          // the cursor ended at offset + n
+            if (n == 1) { out[o] = slot_to_row(a, col, cld<GMEM>(mem + o)); continue; }
+            if (n > kSmall) { flags[0] = 1; continue; }
+            for (int m = 0; m < n; ++m) {
+                const int v = cld<GMEM>(mem + o + m);
+                int rk = 0;
+                for (int j = 0; j < n; ++j) rk += cld<GMEM>(mem + o + j) < v ? 1 : 0;
+                out[o + rk] = slot_to_row(a, col, v);
+            }
+        }
+        __syncthreads();
+        if (flags[0]) {
+            for (int i = wave; i < slots; i += nwave) {
+                const int n = cld<GMEM>(gcnt + i);
+                if (n <= kSmall) continue;
+                const int o = cld<GMEM>(aux + i) - n;
+                for (int m = lane; m < n; m += 64) {
+                    const int v = cld<GMEM>(mem + o + m);
+                    int rk = 0;
+                    for (int j = 0; j < n; ++j) rk += cld<GMEM>(mem + o + j) < v ? 1 : 0;
+                    out[o + rk] = slot_to_row(a, col, v);
+                }
+            }
+        }
+        // bookkeeping counters: one atomic per column and slot
+        if (temporal) {
+            int cand = 0;
+            for (int t = tid; t < a.T - 1; t += nt) cand += a.cand_cnt[t * R + r];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) cand += __shfl_xor(cand, d, 64);
+            if (lane == 0 && cand) atomicAdd(a.counts + STTM_CNT_CANDIDATES, cand);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) nodes += __shfl_xor(nodes, d, 64);
+        if (lane == 0 && nodes) atomicAdd(a.counts + STTM_CNT_NODES, nodes);
+        if (tid == 0) {
+            if (E) atomicAdd(a.counts + STTM_CNT_EDGES, E);
+            if (r == 0) a.counts[STTM_CNT_ITERS] = K;
         }
     }
 }
 
-hipError_t launch_labels(const TemporalArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL(k_labels, dim3(1), dim3(kLabelThreads), 0, stream, a);
+constexpr size_t kColLdsLimit = 160 * 1024 - 1024;      // leave room for the static __shared__ scratch
+
+bool col_labels_use_gmem(const TemporalArgs& a) {
+    return a.force_gmem || sizeof(int) * (size_t)4 * a.max_slots > kColLdsLimit;
+}
+
+hipError_t launch_col_labels(const TemporalArgs& a, bool probe, hipStream_t stream) {
+    const bool gmem = col_labels_use_gmem(a);
+    int nthreads = 256;
+    while (nthreads < kColThreads && nthreads * 2 <= a.max_slots) nthreads *= 2;
+    const size_t smem = gmem ? 0 : sizeof(int) * (size_t)4 * a.max_slots;
+    if (probe) {
+        if (!(a.temporal_thresh > 0.f && a.T > 1)) return hipSuccess;
+        if (gmem) hipLaunchKernelGGL((k_col_labels<false, true>), dim3(a.R), dim3(nthreads), smem, stream, a);
+        else hipLaunchKernelGGL((k_col_labels<false, false>), dim3(a.R), dim3(nthreads), smem, stream, a);
+    } else {
+        if (gmem) hipLaunchKernelGGL((k_col_labels<true, true>), dim3(a.R), dim3(nthreads), smem, stream, a);
+        else hipLaunchKernelGGL((k_col_labels<true, false>), dim3(a.R), dim3(nthreads), smem, stream, a);
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K4: rank.  One workgroup per frame: rows of frames before it (sum of frame_cnt) + a scan of its own
+// H*W origin slots.  row2origin[rank] = origin row of the survivor.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_rank(TemporalArgs a) {
+    __shared__ int wsum[16];
+    const int t = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int HW = a.H * a.W;
+    int before = 0;
+    for (int f = tid; f < t; f += nt) before += a.frame_cnt[f];
+    int base = 0;
+    block_exclusive_scan(before, wsum, &base);
+    const int per = (HW + nt - 1) / nt;
+    const int lo = tid * per < HW ? tid * per : HW, hi = lo + per < HW ? lo + per : HW;
+    int mine = 0;
+    for (int p = lo; p < hi; ++p) mine += a.grp_cnt[t * HW + p] > 0 ? 1 : 0;
+    int tot = 0;
+    int off = base + block_exclusive_scan(mine, wsum, &tot);
+    for (int p = lo; p < hi; ++p) {
+        if (a.grp_cnt[t * HW + p] > 0) a.row2origin[off++] = t * HW + p;
+    }
+    if (t == a.T - 1 && tid == 0) a.counts[STTM_CNT_OUT] = base + tot;
+}
+
+hipError_t launch_rank(const TemporalArgs& a, hipStream_t stream) {
+    hipLaunchKernelGGL(k_rank, dim3(a.T), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Generic single-workgroup label propagation on an explicit edge list (sttm_merge_dst_idx): global
+// memory, agent-scope accesses so phases separated by __syncthreads() see each other's writes.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kLabelThreads = 1024;
+
+__global__ void __launch_bounds__(kLabelThreads) k_label_edges(const int32_t* pairs, int L, int N, int32_t* rep_out,
+                                                               int32_t* rep2, int32_t* emin, int32_t* iters_out) {
+    __shared__ int flag;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    int32_t* cur = rep_out;
+    int32_t* nxt = rep2;
+    for (int i = tid; i < N; i += nt) st_agent(cur + i, i);
+    __syncthreads();
+    int iters = 0;
+    while (true) {
+        for (int e = tid; e < L; e += nt) {
+            const int rd = ld_agent(cur + pairs[2 * e]), rs = ld_agent(cur + pairs[2 * e + 1]);
+            emin[e] = rd < rs ? rd : rs;
+        }
+        if (tid == 0) flag = 0;
+        __syncthreads();
+        for (int e = tid; e < L; e += nt) {
+            const int m = emin[e];
+            __hip_atomic_fetch_min(cur + pairs[2 * e], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_min(cur + pairs[2 * e + 1], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        for (int i = tid; i < N; i += nt) st_agent(nxt + i, ld_agent(cur + ld_agent(cur + i)));
+        __syncthreads();
+        int bad = 0;
+        for (int i = tid; i < N; i += nt) {
+            const int v = ld_agent(nxt + i);
+            if (ld_agent(nxt + v) != v) bad = 1;
+        }
+        if (bad) flag = 1;
+        __syncthreads();
+        const int again = flag;
+        __syncthreads();
+        int32_t* tmp = cur; cur = nxt; nxt = tmp;
+        ++iters;
+        if (!again) break;
+    }
+    if (cur != rep_out) {
+        for (int i = tid; i < N; i += nt) st_agent(rep_out + i, ld_agent(cur + i));
+    }
+    if (tid == 0 && iters_out) *iters_out = iters;
+}
+
+hipError_t launch_label_edges(const int32_t* pairs, int L, int N, int32_t* rep_out, int32_t* rep2, int32_t* emin,
+                              int32_t* iters_out, hipStream_t stream) {
+    hipLaunchKernelGGL(k_label_edges, dim3(1), dim3(kLabelThreads), 0, stream, pairs, L, N, rep_out, rep2, emin, iters_out);
     return hipGetLastError();
 }
 
@@ -303,8 +550,8 @@ __global__ void __launch_bounds__(256) k_group_mean(TemporalArgs a) {
     const int n_out = a.counts[STTM_CNT_OUT];
     const int HW = a.H * a.W;
     for (int row = blockIdx.x * nwave + wave; row < n_out; row += gridDim.x * nwave) {
-        const int off = a.grp_off[row], cnt = a.grp_cnt[row];
         const int origin = a.row2origin[row];
+        const int off = a.grp_off[origin], cnt = a.grp_cnt[origin];
         int patches = 0;
         for (int m = lane; m < cnt; m += 64) {
             const int mem = a.members[off + m];
