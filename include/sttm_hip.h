@@ -107,28 +107,21 @@ int sttm_merge_dst_idx(const int32_t* pairs, int L, int N, int32_t* rep_out, voi
                        void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * ToMe baseline: one bipartite_soft_matching + merge_wavg step (tome_token_merger.py:13-91) on a
- * [n, C] token matrix.  See sttm_tome_workspace_bytes for scratch; outputs hold n - r rows.
+ * ToMe baseline: ONE iteration of tome_per_video's loop (tome_token_merger.py:143-149), i.e.
+ * bipartite_soft_matching (:13-57) + merge_wavg (:77-91) on a [n, C] token matrix.  float32 only.
+ *
+ *   x          [n, C] row-major tokens          size  [n] token sizes, or NULL for all ones (first iteration)
+ *   idx        [n] int64 token ids              r     tokens to remove, 1 <= r <= n / 2 (callers clamp like :26)
+ *   x_out      [n - r, C]   size_out [n - r]    idx_out [n - r]
+ *              rows: the (ceil(n/2) - r) unmerged even tokens in descending best-score order, then every odd token
+ *              in original order with its merged sources folded in (size-weighted average, sources added in rank order)
+ *   node_max_out / node_idx_out   optional [ceil(n/2)] copies of scores.max(-1) (:36) for inspection, may be NULL
+ * Enqueued on `stream` without any host synchronisation; workspace >= sttm_tome_workspace_bytes(n, C, n_head).
  * ------------------------------------------------------------------------------------------------ */
 size_t sttm_tome_workspace_bytes(int n, int C, int n_head);
-
-/*
- * Step 1 (matching): for every even token i, best-matching odd token and its cosine score
- *   node_max[i] = max_j <a_i, b_j>,  node_idx[i] = argmax_j   (first maximum on ties, like torch.max on CPU)
- * with a = m[0::2], b = m[1::2], m = head-mean of x normalised to unit length (no eps).
- * node_max: float32[ceil(n/2)], node_idx: int32[ceil(n/2)].
- */
-int sttm_tome_match(const void* x, int n, int C, int n_head, int dtype, void* workspace, size_t workspace_bytes,
-                    float* node_max, int32_t* node_idx, void* stream);
-
-/*
- * Step 2 (merge): given the ranking `order` (int64[na], descending node_max, produced by the caller's
- * stable sort), r, node_idx, sizes and token ids, writes the n - r merged rows:
- *   [x_a[order[r:]] ... , x_b (+ merged sources, size-weighted average) ...]
- */
-int sttm_tome_merge(const void* x, const float* size, const int64_t* token_idx, int n, int C, int dtype,
-                    const int64_t* order, int r, const int32_t* node_idx, void* workspace, size_t workspace_bytes,
-                    void* x_out, float* size_out, int64_t* token_idx_out, void* stream);
+int sttm_tome_step(const void* x, const float* size, const int64_t* idx, int n, int C, int n_head, int r, int dtype,
+                   void* workspace, size_t workspace_bytes, void* x_out, float* size_out, int64_t* idx_out,
+                   float* node_max_out, int32_t* node_idx_out, void* stream);
 
 #ifdef __cplusplus
 }

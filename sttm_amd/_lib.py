@@ -26,8 +26,7 @@ SIGNATURES = {
     "sttm_profile_last": (_i, [ctypes.POINTER(ctypes.c_float)]),
     "sttm_merge_dst_idx": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "sttm_tome_workspace_bytes": (_sz, [_i, _i, _i]),
-    "sttm_tome_match": (_i, [_vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp]),
-    "sttm_tome_merge": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "sttm_tome_step": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

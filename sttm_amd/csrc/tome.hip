@@ -1,17 +1,369 @@
-// ToMe baseline kernels (K7/K8) -- placeholder entry points until the MFMA matcher lands.
+// K7/K8 -- ToMe bipartite soft matching + size-weighted merge on gfx950 (tome_token_merger.py:13-91).
+//
+// One sttm_tome_step call = one iteration of tome_per_video's loop (tome_token_merger.py:143-149):
+//   k_tome_normalize   head-mean metric, unit rows (no eps), split into even (a) / odd (b) token matrices
+//   k_tome_match       scores = a @ b^T fused with the row max / argmax -- the [na, nb] score matrix
+//                      (629 MB at n = 25 088) is never materialised.  fp32-input MFMA
+//                      (v_mfma_f32_32x32x2_f32: exact fp32 products and accumulation) computes the
+//                      TRANSPOSED tile D[j][i] = b_j . a_i, so every lane owns one a-row i and sees its
+//                      candidates j along its accumulator registers: the running max/argmax needs no
+//                      cross-lane traffic inside the main loop.
+//   hipcub radix sort  ranking of the a-tokens by best score, descending (stable)
+//   k_tome_*           per-destination source lists in rank order, then the size-weighted merge
+// Nothing here depends on data-dependent sizes: the step is enqueued without any host synchronisation.
+#include <hipcub/hipcub.hpp>
+
 #include "sttm_kernels.h"
+
+namespace sttm {
+
+// ---------------------------------------------------------------------------------------------------
+// normalise: m = mean over heads of x.reshape(n, n_head, D); m /= |m| ; a = m[0::2], b = m[1::2]
+// one wave per token row
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_tome_normalize(const float* __restrict__ x, int n, int C, int n_head, int D,
+                                                        float* __restrict__ ahat, float* __restrict__ bhat) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    for (int row = blockIdx.x * nwave + wave; row < n; row += gridDim.x * nwave) {
+        const float* xr = x + (int64_t)row * C;
+        float* out = ((row & 1) ? bhat : ahat) + (int64_t)(row >> 1) * D;
+        float ss = 0.f;
+        for (int d = lane; d < D; d += 64) {
+            float m;
+            if (n_head == 1) {
+                m = xr[d];
+            } else {
+                float s = 0.f;
+                for (int h = 0; h < n_head; ++h) s += xr[h * D + d];
+                m = s / (float)n_head;
+            }
+            out[d] = m;
+            ss = fmaf(m, m, ss);
+        }
+        ss = wave_sum(ss);
+        const float nrm = sqrtf(ss);
+        for (int d = lane; d < D; d += 64) out[d] = out[d] / nrm;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// match: for every a-row i: max_j <a_i, b_j> and the first j that attains it
+// ---------------------------------------------------------------------------------------------------
+constexpr int TM_I = 128;      // a-rows per workgroup
+constexpr int TM_J = 128;      // b-rows per step
+constexpr int TM_K = 32;       // k-depth per LDS stage
+constexpr int TM_LD = TM_I + 1;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ unsigned long long pack_score(float v, int j) {
+    // order-preserving map of the float, then "smaller j wins" on ties (torch.max returns the first maximum)
+    unsigned u = __float_as_uint(v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)u << 32) | (unsigned long long)(0xffffffffu - (unsigned)j);
+}
+
+__global__ void __launch_bounds__(256, 2) k_tome_match(const float* __restrict__ ahat, const float* __restrict__ bhat,
+                                                        int na, int nb, int D, int jsplit,
+                                                        unsigned long long* __restrict__ best /*[na]*/) {
+    __shared__ float As[TM_K][TM_LD];     // As[k][i]
+    __shared__ float Bs[TM_K][TM_LD];     // Bs[k][j]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave & 1, wj = wave >> 1;          // wave tile: 64 (j) x 64 (i)
+    const int itile = blockIdx.x / jsplit, jpart = blockIdx.x % jsplit;
+    const int i0 = itile * TM_I;
+    const int jtiles = (nb + TM_J - 1) / TM_J;
+    const int jt_lo = (int)((long long)jtiles * jpart / jsplit), jt_hi = (int)((long long)jtiles * (jpart + 1) / jsplit);
+
+    // staging map: 8 threads per row (8 x float4 = 32 k), 32 rows per pass, 4 passes per 128-row tile
+    const int srow = tid >> 3, skq = (tid & 7) * 4;
+
+    float bestv[2] = {-INFINITY, -INFINITY};
+    int bestj[2] = {0x7fffffff, 0x7fffffff};
+    const int lcol = lane & 31, lhalf = lane >> 5;
+
+    for (int jt = jt_lo; jt < jt_hi; ++jt) {
+        const int j0 = jt * TM_J;
+        f32x16 acc[2][2];     // [j-subtile][i-subtile]
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[p][q][e] = 0.f;
+
+        for (int k0 = 0; k0 < D; k0 += TM_K) {
+            // stage: global (row-major, k contiguous) -> registers -> LDS transposed [k][row]
+            float4 ra[4], rb[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int ri = i0 + p * 32 + srow, rj = j0 + p * 32 + srow;
+                const int kk = k0 + skq;
+                ra[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+                rb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ri < na && kk + 3 < D) ra[p] = *reinterpret_cast<const float4*>(ahat + (int64_t)ri * D + kk);
+                else if (ri < na) { float t[4] = {0, 0, 0, 0}; for (int c = 0; c < 4; ++c) if (kk + c < D) t[c] = ahat[(int64_t)ri * D + kk + c]; ra[p] = make_float4(t[0], t[1], t[2], t[3]); }
+                if (rj < nb && kk + 3 < D) rb[p] = *reinterpret_cast<const float4*>(bhat + (int64_t)rj * D + kk);
+                else if (rj < nb) { float t[4] = {0, 0, 0, 0}; for (int c = 0; c < 4; ++c) if (kk + c < D) t[c] = bhat[(int64_t)rj * D + kk + c]; rb[p] = make_float4(t[0], t[1], t[2], t[3]); }
+            }
+            __syncthreads();          // previous stage fully consumed
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int r = p * 32 + srow;
+                As[skq + 0][r] = ra[p].x; As[skq + 1][r] = ra[p].y; As[skq + 2][r] = ra[p].z; As[skq + 3][r] = ra[p].w;
+                Bs[skq + 0][r] = rb[p].x; Bs[skq + 1][r] = rb[p].y; Bs[skq + 2][r] = rb[p].z; Bs[skq + 3][r] = rb[p].w;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < TM_K; kk += 2) {
+                // MFMA A operand = b rows (j), B operand = a rows (i):  D[j][i] += sum_k b[j][k] * a[i][k]
+                float fb[2], fa[2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) fb[p] = Bs[kk + lhalf][wj * 64 + p * 32 + lcol];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) fa[q] = As[kk + lhalf][wi * 64 + q * 32 + lcol];
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[p], fa[q], acc[p][q], 0, 0, 0);
+            }
+        }
+        // running max over this tile: lane owns column i = wi*64 + q*32 + lcol; rows j = (e&3) + 8*(e>>2) + 4*lhalf
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int j = j0 + wj * 64 + p * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
+                    const float v = acc[p][q][e];
+                    if (j < nb && (v > bestv[q] || (v == bestv[q] && j < bestj[q]))) { bestv[q] = v; bestj[q] = j; }
+                }
+    }
+    // publish: packed 64-bit max per a-row (combines the two lane halves, the two j-waves and the j-splits)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int i = i0 + wi * 64 + q * 32 + lcol;
+        if (i < na && bestj[q] != 0x7fffffff) atomicMax(best + i, pack_score(bestv[q], bestj[q]));
+    }
+}
+
+__global__ void k_tome_unpack(const unsigned long long* __restrict__ best, int na, float* __restrict__ node_max,
+                              int* __restrict__ node_idx, int* __restrict__ iota) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= na) return;
+    const unsigned long long b = best[i];
+    unsigned u = (unsigned)(b >> 32);
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    node_max[i] = b ? __uint_as_float(u) : __uint_as_float(0x7fc00000u);       // no finite score at all: NaN row
+    node_idx[i] = b ? (int)(0xffffffffu - (unsigned)(b & 0xffffffffu)) : 0;
+    iota[i] = i;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// merge bookkeeping: sources (rank < r) grouped per destination b-token, in rank order
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_tome_count(const int* __restrict__ order, const int* __restrict__ node_idx, int r, int* __restrict__ cnt) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < r) atomicAdd(cnt + node_idx[order[k]], 1);
+}
+
+__global__ void __launch_bounds__(1024) k_tome_scan(const int* __restrict__ cnt, int nb, int* __restrict__ off) {
+    // single workgroup exclusive scan (nb is a few 10^4 at most)
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = nt >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += nt) {
+        const int i = base + tid;
+        const int v = i < nb ? cnt[i] : 0;
+        int inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int pre = carry;
+        for (int w = 0; w < wave; ++w) pre += wsum[w];
+        if (i < nb) off[i] = pre + inc - v;
+        __syncthreads();
+        if (tid == nt - 1) carry = pre + inc;
+        __syncthreads();
+    }
+    if (tid == 0) off[nb] = carry;
+}
+
+__global__ void k_tome_fill(const int* __restrict__ order, const int* __restrict__ node_idx, int r, const int* __restrict__ off,
+                            int* __restrict__ cur, int* __restrict__ lists /* rank positions k */) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < r) {
+        const int d = node_idx[order[k]];
+        lists[off[d] + atomicAdd(cur + d, 1)] = k;
+    }
+}
+
+// one wave per output row.  rows [0, na - r): unmerged a-tokens in rank order; rows [na - r, n - r): b-tokens
+__global__ void __launch_bounds__(256) k_tome_merge(const float* __restrict__ x, const float* __restrict__ size,
+                                                    const int64_t* __restrict__ idx, int n, int C, int na, int nb, int r,
+                                                    const int* __restrict__ order, const int* __restrict__ off,
+                                                    int* __restrict__ lists, float* __restrict__ x_out,
+                                                    float* __restrict__ size_out, int64_t* __restrict__ idx_out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    const int n_out = n - r;
+    for (int row = blockIdx.x * nwave + wave; row < n_out; row += gridDim.x * nwave) {
+        if (row < na - r) {
+            const int tok = 2 * order[r + row];                   // unmerged a-token: (x*size)/size
+            const float s = size ? size[tok] : 1.f;
+            for (int c = lane; c < C; c += 64) x_out[(int64_t)row * C + c] = __fmul_rn(x[(int64_t)tok * C + c], s) / s;
+            if (lane == 0) { size_out[row] = s; idx_out[row] = idx[tok]; }
+            continue;
+        }
+        const int j = row - (na - r);
+        const int tok = 2 * j + 1;
+        const int o = off[j], cnt = off[j + 1] - o;
+        // order this destination's sources by rank (ascending k)
+        if (cnt > 1) {
+            if (cnt <= 64) {                                      // the usual case: rank sort in registers
+                const int v = lane < cnt ? lists[o + lane] : 0x7fffffff;
+                int rk = 0;
+                for (int m = 0; m < cnt; ++m) rk += __shfl(v, m, 64) < v ? 1 : 0;
+                if (lane < cnt) lists[o + rk] = v;
+            } else {                                              // pathological inputs: selection sort, O(cnt^2 / 64)
+                for (int m = 0; m < cnt - 1; ++m) {
+                    int mn = 0x7fffffff, mp = -1;
+                    for (int q = m + lane; q < cnt; q += 64) { const int v = lists[o + q]; if (v < mn) { mn = v; mp = q; } }
+                    for (int d = 32; d >= 1; d >>= 1) {
+                        const int omn = __shfl_xor(mn, d, 64), omp = __shfl_xor(mp, d, 64);
+                        if (omn < mn) { mn = omn; mp = omp; }
+                    }
+                    if (lane == 0 && mp != m) { const int tmp = lists[o + m]; lists[o + m] = mn; lists[o + mp] = tmp; }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        const float sb = size ? size[tok] : 1.f;
+        float stot = sb;
+        for (int m = 0; m < cnt; ++m) {
+            const int atok = 2 * order[lists[o + m]];
+            stot = __fadd_rn(stot, size ? size[atok] : 1.f);
+        }
+        for (int c = lane; c < C; c += 64) {
+            float acc = __fmul_rn(x[(int64_t)tok * C + c], sb);          // no fma contraction: the reference rounds x*size
+            for (int m = 0; m < cnt; ++m) {
+                const int atok = 2 * order[lists[o + m]];
+                const float sa = size ? size[atok] : 1.f;
+                acc = __fadd_rn(acc, __fmul_rn(x[(int64_t)atok * C + c], sa));
+            }
+            x_out[(int64_t)row * C + c] = acc / stot;
+        }
+        if (lane == 0) { size_out[row] = stot; idx_out[row] = idx[tok]; }
+    }
+}
+
+struct TomePlan {
+    int na, nb, D;
+    size_t off_ahat, off_bhat, off_best, off_nmax, off_nidx, off_iota, off_keys, off_order, off_cnt, off_cur, off_off,
+        off_lists, off_cub, cub_bytes, total;
+};
+
+static inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
+
+static int tome_plan(int n, int C, int n_head, TomePlan* p) {
+    if (n < 2 || C < 1 || n_head < 1 || C % n_head) return -1;
+    p->na = (n + 1) / 2; p->nb = n / 2; p->D = C / n_head;
+    size_t o = 0;
+    p->off_ahat = o; o = al(o + (size_t)p->na * p->D * 4);
+    p->off_bhat = o; o = al(o + (size_t)(p->nb > 0 ? p->nb : 1) * p->D * 4);
+    p->off_best = o; o = al(o + (size_t)p->na * 8);
+    p->off_nmax = o; o = al(o + (size_t)p->na * 4);
+    p->off_nidx = o; o = al(o + (size_t)p->na * 4);
+    p->off_iota = o; o = al(o + (size_t)p->na * 4);
+    p->off_keys = o; o = al(o + (size_t)p->na * 4);
+    p->off_order = o; o = al(o + (size_t)p->na * 4);
+    p->off_cnt = o; o = al(o + (size_t)(p->nb + 1) * 4);
+    p->off_cur = o; o = al(o + (size_t)(p->nb + 1) * 4);
+    p->off_off = o; o = al(o + (size_t)(p->nb + 2) * 4);
+    p->off_lists = o; o = al(o + (size_t)p->na * 4);
+    size_t cub = 0;
+    hipcub::DeviceRadixSort::SortPairsDescending(nullptr, cub, (const float*)nullptr, (float*)nullptr, (const int*)nullptr,
+                                                 (int*)nullptr, p->na);
+    p->cub_bytes = cub;
+    p->off_cub = o; o = al(o + cub);
+    p->total = o;
+    return 0;
+}
+
+}  // namespace sttm
 
 extern "C" {
 
-size_t sttm_tome_workspace_bytes(int, int, int) { return 0; }
-
-int sttm_tome_match(const void*, int, int, int, int, void*, size_t, float*, int32_t*, void*) {
-    return STTM_ERR_UNSUPPORTED;
+size_t sttm_tome_workspace_bytes(int n, int C, int n_head) {
+    sttm::TomePlan p;
+    if (sttm::tome_plan(n, C, n_head, &p) != 0) return 0;
+    return p.total;
 }
 
-int sttm_tome_merge(const void*, const float*, const int64_t*, int, int, int, const int64_t*, int, const int32_t*,
-                    void*, size_t, void*, float*, int64_t*, void*) {
-    return STTM_ERR_UNSUPPORTED;
+int sttm_tome_step(const void* x_, const float* size, const int64_t* idx, int n, int C, int n_head, int r, int dtype,
+                   void* workspace, size_t workspace_bytes, void* x_out_, float* size_out, int64_t* idx_out,
+                   float* node_max_out, int32_t* node_idx_out, void* stream_) {
+    using namespace sttm;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (dtype != STTM_F32) return STTM_ERR_UNSUPPORTED;
+    if (!x_ || !idx || !workspace || !x_out_ || !size_out || !idx_out) return STTM_ERR_ARG;
+    TomePlan p;
+    if (tome_plan(n, C, n_head, &p) != 0) return STTM_ERR_ARG;
+    if (workspace_bytes < p.total) return STTM_ERR_ARG;
+    if (r < 1 || r > p.nb) return STTM_ERR_ARG;              // callers clamp r = min(r, n // 2) like the reference
+    const float* x = reinterpret_cast<const float*>(x_);
+    float* x_out = reinterpret_cast<float*>(x_out_);
+    char* ws = reinterpret_cast<char*>(workspace);
+    float* ahat = reinterpret_cast<float*>(ws + p.off_ahat);
+    float* bhat = reinterpret_cast<float*>(ws + p.off_bhat);
+    unsigned long long* best = reinterpret_cast<unsigned long long*>(ws + p.off_best);
+    float* nmax = reinterpret_cast<float*>(ws + p.off_nmax);
+    int* nidx = reinterpret_cast<int*>(ws + p.off_nidx);
+    int* iota = reinterpret_cast<int*>(ws + p.off_iota);
+    float* keys = reinterpret_cast<float*>(ws + p.off_keys);
+    int* order = reinterpret_cast<int*>(ws + p.off_order);
+    int* cnt = reinterpret_cast<int*>(ws + p.off_cnt);
+    int* cur = reinterpret_cast<int*>(ws + p.off_cur);
+    int* off = reinterpret_cast<int*>(ws + p.off_off);
+    int* lists = reinterpret_cast<int*>(ws + p.off_lists);
+
+    hipMemsetAsync(best, 0, (size_t)p.na * 8, stream);
+    hipMemsetAsync(cnt, 0, p.off_off - p.off_cnt, stream);      // cnt and cur
+    {
+        int grid = (n + 3) / 4; if (grid > 8192) grid = 8192;
+        hipLaunchKernelGGL(k_tome_normalize, dim3(grid), dim3(256), 0, stream, x, n, C, n_head, p.D, ahat, bhat);
+    }
+    {
+        const int itiles = (p.na + TM_I - 1) / TM_I;
+        const int jtiles = (p.nb + TM_J - 1) / TM_J;
+        int jsplit = (512 + itiles - 1) / itiles;
+        if (jsplit > jtiles) jsplit = jtiles;
+        if (jsplit < 1) jsplit = 1;
+        hipLaunchKernelGGL(k_tome_match, dim3(itiles * jsplit), dim3(256), 0, stream, ahat, bhat, p.na, p.nb, p.D, jsplit, best);
+    }
+    hipLaunchKernelGGL(k_tome_unpack, dim3((p.na + 255) / 256), dim3(256), 0, stream, best, p.na, nmax, nidx, iota);
+    size_t cub = p.cub_bytes;
+    hipcub::DeviceRadixSort::SortPairsDescending(ws + p.off_cub, cub, nmax, keys, iota, order, p.na, 0, 32, stream);
+    hipLaunchKernelGGL(k_tome_count, dim3((r + 255) / 256), dim3(256), 0, stream, order, nidx, r, cnt);
+    hipLaunchKernelGGL(k_tome_scan, dim3(1), dim3(1024), 0, stream, cnt, p.nb, off);
+    hipLaunchKernelGGL(k_tome_fill, dim3((r + 255) / 256), dim3(256), 0, stream, order, nidx, r, off, cur, lists);
+    {
+        int grid = (n - r + 3) / 4; if (grid > 8192) grid = 8192;
+        hipLaunchKernelGGL(k_tome_merge, dim3(grid), dim3(256), 0, stream, x, size, idx, n, C, p.na, p.nb, r, order, off, lists,
+                           x_out, size_out, idx_out);
+    }
+    if (node_max_out) hipMemcpyAsync(node_max_out, nmax, (size_t)p.na * 4, hipMemcpyDeviceToDevice, stream);
+    if (node_idx_out) hipMemcpyAsync(node_idx_out, nidx, (size_t)p.na * 4, hipMemcpyDeviceToDevice, stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? STTM_OK : STTM_ERR_LAUNCH;
 }
 
 }  // extern "C"

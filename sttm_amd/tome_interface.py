@@ -1,0 +1,67 @@
+"""ToMe baseline behind the reference's L1 boundary (`token_merging_utils/tome_interface.py:3-9`).
+
+`get_tome_features(_video_feature, prune_ratio, tome_ver, n_head=1)` keeps the reference's dispatch and its
+quirks: "video" works, "frame" raises RuntimeError for T > 1, "snippet" and unknown
+versions return None.  The per-video loop (tome_token_merger.py:133-152) runs on the device with no host
+synchronisation at all: the number of tokens after every iteration is known on the host in advance.
+"""
+import math
+
+import torch
+
+from . import _lib
+
+
+def _tome_video(x_tchw, prune_ratio, n_head):
+    if not x_tchw.is_cuda:
+        raise RuntimeError("sttm_amd runs on the GPU only: the input must be a CUDA (ROCm) tensor; "
+                           "there is no CPU fallback")
+    if x_tchw.dtype != torch.float32:
+        raise NotImplementedError("the device ToMe path is float32 only for now")
+    lib = _lib.load()
+    T, C, H, W = x_tchw.shape
+    x = x_tchw.permute(0, 2, 3, 1).reshape(T * H * W, C)           # view for the production layout
+    if not x.is_contiguous():
+        x = x.contiguous()
+    dev = x.device
+    n = x.shape[0]
+    target = math.ceil(n * (1 - prune_ratio))
+    idx = torch.arange(n, device=dev, dtype=torch.int64)
+    size = None
+    first = True
+    stream = torch.cuda.current_stream(dev)
+    with torch.cuda.device(dev):
+        while first or n > target:
+            first = False
+            r = min(n - target, n // 2)
+            if r <= 0:
+                # the reference's do_nothing(x, mode=None) stand-in is called as merge(x*size, token_idx, mode="sum")
+                raise TypeError("do_nothing() got multiple values for argument 'mode' "
+                                "(prune_ratio <= 0 is unusable in the reference)")
+            nbytes = lib.sttm_tome_workspace_bytes(n, C, int(n_head))
+            if nbytes == 0:
+                raise ValueError(f"bad ToMe configuration n={n} C={C} n_head={n_head}")
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            x_out = torch.empty((n - r, C), dtype=torch.float32, device=dev)
+            size_out = torch.empty(n - r, dtype=torch.float32, device=dev)
+            idx_out = torch.empty(n - r, dtype=torch.int64, device=dev)
+            rc = lib.sttm_tome_step(x.data_ptr(), size.data_ptr() if size is not None else None, idx.data_ptr(),
+                                    n, C, int(n_head), r, _lib.STTM_F32, ws.data_ptr(), nbytes,
+                                    x_out.data_ptr(), size_out.data_ptr(), idx_out.data_ptr(), None, None,
+                                    stream.cuda_stream)
+            _lib.raise_for(rc)
+            x, size, idx, n = x_out, size_out, idx_out, n - r
+    return x, idx
+
+
+def get_tome_features(_video_feature, prune_ratio, tome_ver, n_head=1):
+    if tome_ver == "frame":
+        if _video_feature.shape[0] > 1:
+            # tome_per_frame keeps a [1, n, 1] token-index tensor next to [T, n, C] features and torch.gather
+            # raises (tome_token_merger.py:52-54)
+            raise RuntimeError("Sizes of tensors must match except in dimension 1: tome_ver='frame' is broken in "
+                               "the reference for T > 1 (token index batch 1 vs T)")
+        return _tome_video(_video_feature, prune_ratio, n_head)
+    if tome_ver == "video":
+        return _tome_video(_video_feature, prune_ratio, n_head)
+    return None            # "snippet" is a stub upstream; unknown versions fall through the reference's if/elif
