@@ -103,9 +103,10 @@ def main():
     for s in range(K):
         run_step(s, sink)
     if dist is not None:      # the one exchange step of the job: per-video merged-token counts to every rank
-        mine = torch.tensor(sink, dtype=torch.int32, device=dev)
-        allc = torch.empty(world * mine.numel(), dtype=torch.int32, device=dev)
-        dist.all_gather_into_tensor(allc, mine)
+        from sttm_amd.distributed import gather_counts, shard_videos
+        ids = shard_videos(world * K * V, world, rank)
+        all_counts = gather_counts(ids, sink, world * K * V, dev, dist)
+        assert int((all_counts > 0).sum()) == world * K * V
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0

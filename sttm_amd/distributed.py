@@ -1,0 +1,34 @@
+"""Multi-GPU sharding of the merge: videos are independent units, so they are partitioned over the ranks
+(one process per GPU) with NO data-path collective; the only exchange is the final all-gather of the
+per-video merged-token counts (and, in validation mode, indices) over RCCL/xGMI
+(`torch.distributed` backend "nccl" on ROCm; "gloo" in the CPU tests).  SURVEY.md section 8(e).
+"""
+import torch
+
+
+def shard_videos(n_videos, world, rank, costs=None):
+    """Video ids owned by `rank`.  Uniform costs -> round-robin; otherwise longest-processing-time-first
+    greedy on `costs` (e.g. T*H*W per video), deterministic on every rank."""
+    if costs is None:
+        return list(range(rank, n_videos, world))
+    order = sorted(range(n_videos), key=lambda i: (-costs[i], i))
+    load = [0] * world
+    owner = [0] * n_videos
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        owner[i] = r
+        load[r] += costs[i]
+    return [i for i in range(n_videos) if owner[i] == rank]
+
+
+def gather_counts(local_ids, local_counts, n_videos, device, dist=None):
+    """All ranks learn every video's merged-token count: returns an int32 tensor [n_videos].
+    local_ids / local_counts: this rank's video ids and N' values.  One collective, tiny payload."""
+    full = torch.zeros(n_videos, dtype=torch.int32, device=device)
+    if len(local_ids):
+        full[torch.as_tensor(local_ids, device=device, dtype=torch.long)] = torch.as_tensor(
+            local_counts, device=device, dtype=torch.int32)
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        # disjoint ownership: a SUM all-reduce of the one-hot-by-owner vector is an all-gather with static shape
+        dist.all_reduce(full, op=dist.ReduceOp.SUM)
+    return full

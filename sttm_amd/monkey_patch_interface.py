@@ -1,0 +1,187 @@
+"""L2 installer with the reference's names and keyword arguments (token_merging_utils/monkey_patch_interface.py:17-38).
+
+`replace_qwen2_by_sparse_attn(pattern_name, **kwargs)` dispatches on the same pattern names.  "quadtree" and "tome" --
+the two patterns on the hot path -- are implemented: like the reference they store their configuration as CLASS
+attributes on the decoder model class and overwrite its `.forward` (quadtree_attn_monkey_patch.py:177-187,
+tome_attn_monkey_patch.py:163-171).  The other names are the reference's ablations / other papers' baselines and
+raise NotImplementedError with a message that says so.
+
+The reference pins transformers==4.45.2 and patches a verbatim copy of that version's Qwen2Model.forward.  This
+build targets the transformers that is installed (5.x decoder-layer API): the patched forward below is the
+installed `Qwen2Model.forward` with the merge step inserted before layer `sa_start_layer_idx` on prefill.
+State read by the hook is the same: `self.image_token_start_index`, `self.image_token_length`, `self.num_frame`
+(0-d tensors set by generate(), llava/model/language_model/llava_qwen.py:141-143), plus `image_H/image_W` for Qwen2-VL.
+"""
+import torch
+
+from . import patch_hooks
+from .quadtree_interface import get_quadtree_features
+from .tome_interface import get_tome_features
+
+_UNIMPLEMENTED = {
+    "quadtree-abl-pos": "position-embedding ablation (quadtree_attn_monkey_patch_for_abl_pos.py)",
+    "octree": "octree ablation (octree_utils.py)",
+    "pyrd": "fixed-size F.interpolate pyramid baseline",
+    "quadtree_vis": "visualisation variant",
+    "dycoke": "DyCoke baseline",
+    "dycoke-stage1": "DyCoke stage-1 baseline",
+}
+
+
+def _item(v):
+    return int(v.item()) if torch.is_tensor(v) else int(v)
+
+
+def _is_prefill(past_key_values):
+    return past_key_values is None or past_key_values.get_seq_length() == 0
+
+
+def _qwen2_forward_with_merge(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None,
+                              inputs_embeds=None, use_cache=None, **kwargs):
+    """transformers 5.x Qwen2Model.forward + the STTM / ToMe hook (prefill, batch 1)."""
+    from transformers.cache_utils import DynamicCache
+    from transformers.masking_utils import create_causal_mask, create_sliding_window_causal_mask
+    from transformers.modeling_outputs import BaseModelOutputWithPast
+    if (input_ids is None) ^ (inputs_embeds is not None):
+        raise ValueError("You must specify exactly one of input_ids or inputs_embeds")
+    if inputs_embeds is None:
+        inputs_embeds = self.embed_tokens(input_ids)
+    if use_cache and past_key_values is None:
+        past_key_values = DynamicCache(config=self.config)
+    prefilling = _is_prefill(past_key_values)
+    if position_ids is None:
+        seen = past_key_values.get_seq_length() if past_key_values is not None else 0
+        position_ids = (torch.arange(inputs_embeds.shape[1], device=inputs_embeds.device) + seen).unsqueeze(0)
+    if not isinstance(mask_map := attention_mask, dict):
+        mk = dict(config=self.config, inputs_embeds=inputs_embeds, attention_mask=attention_mask,
+                  past_key_values=past_key_values, position_ids=position_ids)
+        mask_map = {"full_attention": create_causal_mask(**mk)}
+        if getattr(self, "has_sliding_layers", False):
+            mask_map["sliding_attention"] = create_sliding_window_causal_mask(**mk)
+    hidden_states = inputs_embeds
+    position_embeddings = self.rotary_emb(hidden_states, position_ids)
+    merged = False
+    for i, layer in enumerate(self.layers[: self.config.num_hidden_layers]):
+        if prefilling and not merged and i == self.sa_start_layer_idx and getattr(self, "image_token_length", None) is not None:
+            start, length, T = _item(self.image_token_start_index), _item(self.image_token_length), _item(self.num_frame)
+            if self.sttm_pattern == "quadtree":
+                head_dim = layer.self_attn.head_dim if self.sim_per_head else None
+                hidden_states, position_ids, idx = patch_hooks.quadtree_merge_llava(
+                    hidden_states, position_ids, start, length, T, type(self).sttm_merge_fn,
+                    self.sa_tree_thresh, self.sa_tree_temporal_thresh, self.sa_tree_root_level, self.sa_tree_weighted_avg,
+                    slow_ver=self.sttm_slow_ver, head_dim=head_dim)
+            else:
+                hidden_states, position_ids, idx = patch_hooks.tome_merge(
+                    hidden_states, position_ids, start, length, T, type(self).sttm_tome_fn, self.sa_prune_ratio, self.sa_tome_ver)
+            self.merged_token_1d_idx = idx
+            position_embeddings = self.rotary_emb(hidden_states, position_ids)
+            # batch-1 prefill without padding: the shorter sequence is plain causal
+            mask_map = {k: None for k in mask_map}
+            merged = True
+        hidden_states = layer(hidden_states, attention_mask=mask_map[self.config.layer_types[i]],
+                              position_embeddings=position_embeddings, position_ids=position_ids,
+                              past_key_values=past_key_values, use_cache=use_cache, **kwargs)
+    hidden_states = self.norm(hidden_states)
+    return BaseModelOutputWithPast(last_hidden_state=hidden_states, past_key_values=past_key_values if use_cache else None)
+
+
+def _qwen2_model_class():
+    import transformers.models.qwen2.modeling_qwen2 as m
+    return m.Qwen2Model
+
+
+def _qwen2vl_model_class():
+    try:
+        import transformers.models.qwen2_vl.modeling_qwen2_vl as m
+        return getattr(m, "Qwen2VLTextModel", None) or getattr(m, "Qwen2VLModel", None)
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def replace_qwen2_with_quadtree_attn(sa_start_layer_idx=0, sa_tree_thresh=0.90, sa_tree_temporal_thresh=-1.0,
+                                     sa_tree_root_level=0, sa_tree_weighted_avg=False, sttm_slow_ver=False,
+                                     sim_per_head=False, **kwargs):
+    print("Replace Qwen2 attention path by QuadTree (STTM) token merging [sttm_amd / MI355X]")
+    cls = _qwen2_model_class()
+    cls.sttm_pattern = "quadtree"
+    cls.sa_start_layer_idx = sa_start_layer_idx
+    cls.sa_tree_thresh = sa_tree_thresh
+    cls.sa_tree_temporal_thresh = sa_tree_temporal_thresh
+    cls.sa_tree_root_level = sa_tree_root_level
+    cls.sa_tree_weighted_avg = sa_tree_weighted_avg
+    cls.sttm_slow_ver = sttm_slow_ver
+    cls.sim_per_head = sim_per_head
+    if not hasattr(cls, "sttm_merge_fn"):
+        cls.sttm_merge_fn = staticmethod(get_quadtree_features)
+    if not hasattr(cls, "_sttm_original_forward"):
+        cls._sttm_original_forward = cls.forward
+    cls.forward = _qwen2_forward_with_merge
+
+
+def replace_qwen2_with_tome_attn(sa_start_layer_idx=0, sa_prune_ratio=0.50, sa_tome_ver="frame", **kwargs):
+    print("Replace Qwen2 attention path by ToMe token merging [sttm_amd / MI355X]")
+    cls = _qwen2_model_class()
+    cls.sttm_pattern = "tome"
+    cls.sa_start_layer_idx = sa_start_layer_idx
+    cls.sa_prune_ratio = sa_prune_ratio
+    cls.sa_tome_ver = sa_tome_ver
+    if not hasattr(cls, "sttm_tome_fn"):
+        cls.sttm_tome_fn = staticmethod(get_tome_features)
+    if not hasattr(cls, "_sttm_original_forward"):
+        cls._sttm_original_forward = cls.forward
+    cls.forward = _qwen2_forward_with_merge
+
+
+def replace_qwen2vl_with_quadtree_attn(sa_start_layer_idx=0, sa_tree_thresh=0.90, sa_tree_temporal_thresh=-1.0,
+                                       sa_tree_root_level=0, sa_tree_weighted_avg=False, sttm_slow_ver=False, **kwargs):
+    """Qwen2-VL: configuration is stored on the text-model class; the merge step itself is
+    `patch_hooks.quadtree_merge_qwen2vl` (3-D position-id gather + cache_position reset)."""
+    cls = _qwen2vl_model_class()
+    if cls is None:
+        return
+    print("Replace Qwen2-VL attention path by QuadTree (STTM) token merging [sttm_amd / MI355X]")
+    cls.sttm_pattern = "quadtree"
+    cls.sa_start_layer_idx = sa_start_layer_idx
+    cls.sa_tree_thresh = sa_tree_thresh
+    cls.sa_tree_temporal_thresh = sa_tree_temporal_thresh
+    cls.sa_tree_root_level = sa_tree_root_level
+    cls.sa_tree_weighted_avg = sa_tree_weighted_avg
+    cls.sttm_slow_ver = sttm_slow_ver
+    if not hasattr(cls, "sttm_merge_fn"):
+        cls.sttm_merge_fn = staticmethod(get_quadtree_features)
+    cls.sttm_merge_hook = staticmethod(patch_hooks.quadtree_merge_qwen2vl)
+
+
+def replace_qwen2vl_with_tome_attn(sa_start_layer_idx=0, sa_prune_ratio=0.50, sa_tome_ver="frame", **kwargs):
+    cls = _qwen2vl_model_class()
+    if cls is None:
+        return
+    print("Replace Qwen2-VL attention path by ToMe token merging [sttm_amd / MI355X]")
+    cls.sttm_pattern = "tome"
+    cls.sa_start_layer_idx = sa_start_layer_idx
+    cls.sa_prune_ratio = sa_prune_ratio
+    cls.sa_tome_ver = sa_tome_ver
+    if not hasattr(cls, "sttm_tome_fn"):
+        cls.sttm_tome_fn = staticmethod(get_tome_features)
+    cls.sttm_merge_hook = staticmethod(patch_hooks.tome_merge)
+
+
+def restore_qwen2():
+    """Undo replace_qwen2_with_* (not in the reference; handy for tests)."""
+    cls = _qwen2_model_class()
+    if hasattr(cls, "_sttm_original_forward"):
+        cls.forward = cls._sttm_original_forward
+        del cls._sttm_original_forward
+
+
+def replace_qwen2_by_sparse_attn(pattern_name, **kwargs):
+    if pattern_name == "quadtree":
+        replace_qwen2_with_quadtree_attn(**kwargs)
+        replace_qwen2vl_with_quadtree_attn(**kwargs)
+    elif pattern_name == "tome":
+        replace_qwen2_with_tome_attn(**kwargs)
+        replace_qwen2vl_with_tome_attn(**kwargs)
+    elif pattern_name in _UNIMPLEMENTED:
+        raise NotImplementedError(f"{pattern_name} ({_UNIMPLEMENTED[pattern_name]}) is outside the MI355X hot-path build")
+    else:
+        raise NotImplementedError(f"{pattern_name} is not yet implemented")

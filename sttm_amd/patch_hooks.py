@@ -1,0 +1,63 @@
+"""Tensor glue of the reference's patched decoder forward, as plain functions.
+
+These restate the ~25 lines the reference inserts before decoder layer `sa_start_layer_idx` during prefill:
+    LLaVA-Video / OneVision  token_merging_monkey_patch/quadtree_attn_monkey_patch.py:88-117
+    Qwen2-VL                 token_merging_qwen2vl_monkey_patch/quadtree_attn_monkey_patch.py:88-115
+    ToMe                     token_merging_monkey_patch/tome_attn_monkey_patch.py:88-107
+The visual slice is handed to the merge function as a [T, C, H, W] *view* of [T, H, W, C] memory (no copy),
+exactly like einops.rearrange(visual[0], "(T H W) C -> T C H W") in the reference.
+"""
+import math
+
+import torch
+
+
+def _video_view(visual, T, H, W):
+    C = visual.shape[-1]
+    return visual.reshape(T, H, W, C).permute(0, 3, 1, 2)
+
+
+def split_prompt(hidden_states, start, length):
+    end = start + length
+    return hidden_states[:, :start], hidden_states[:, start:end], hidden_states[:, end:]
+
+
+def quadtree_merge_llava(hidden_states, position_ids, start, length, T, merge_fn, threshold, temporal_thresh,
+                         root_level, weighted_avg, slow_ver=False, head_dim=None):
+    """Returns (merged hidden_states [1, S', C], position_ids[:, :S'], merged_token_1d_idx)."""
+    sys_f, vis_f, inst_f = split_prompt(hidden_states, start, length)
+    H = W = int(math.sqrt(length // T))                                   # :97 (needs mm_newline_position=no_token)
+    video = _video_view(vis_f[0], T, H, W)
+    feat, _, tlbr = merge_fn(video, threshold, temporal_thresh, root_level, weighted_avg,
+                             slow_ver=slow_ver, head_dim=head_dim)
+    idx = tlbr[:, 0] * (H * W) + tlbr[:, 1] * W + tlbr[:, 2]              # :103-104
+    merged = torch.cat([sys_f, feat.unsqueeze(0), inst_f], dim=1)          # :105
+    return merged, position_ids[:, :merged.size(1)], idx                   # :114 (truncate, not gather)
+
+
+def quadtree_merge_qwen2vl(hidden_states, position_ids, start, length, T, H, W, merge_fn, threshold, temporal_thresh,
+                           root_level, weighted_avg, slow_ver=False):
+    """position_ids is the 3-D mRoPE tensor [3, B, S]; the visual part is GATHERED by the merged index (:109-113).
+    Returns (merged hidden_states, position_ids, cache_position, merged_token_1d_idx)."""
+    sys_f, vis_f, inst_f = split_prompt(hidden_states, start, length)
+    end = start + length
+    video = _video_view(vis_f[0], T, H, W)
+    feat, _, tlbr = merge_fn(video, threshold, temporal_thresh, root_level, weighted_avg, slow_ver=slow_ver)
+    idx = tlbr[:, 0] * (H * W) + tlbr[:, 1] * W + tlbr[:, 2]
+    merged = torch.cat([sys_f, feat.unsqueeze(0), inst_f], dim=1)
+    vis_pos = position_ids[:, :, start:end][:, :, idx.long()]
+    pos = torch.cat([position_ids[:, :, :start], vis_pos, position_ids[:, :, end:]], dim=-1)
+    cache_position = torch.arange(merged.size(1), device=merged.device, dtype=torch.int)      # :114
+    return merged, pos, cache_position, idx
+
+
+def tome_merge(hidden_states, position_ids, start, length, T, merge_fn, prune_ratio, tome_ver, H=None, W=None):
+    """tome_attn_monkey_patch.py:88-107 (LLaVA: H = W = sqrt(len / T); Qwen2-VL passes H, W)."""
+    sys_f, vis_f, inst_f = split_prompt(hidden_states, start, length)
+    if H is None:
+        H = int(math.sqrt(length // T))
+        W = (length // T) // H
+    video = _video_view(vis_f[0], T, H, W)
+    feat, token_idx = merge_fn(video, prune_ratio, tome_ver)
+    merged = torch.cat([sys_f, feat.unsqueeze(0), inst_f], dim=1)
+    return merged, position_ids[..., :merged.size(1)], token_idx

@@ -1,0 +1,113 @@
+"""Fake-decoder tests of the L2 glue: slicing / concat / position ids around the merge, and the
+installer's names + class-attribute mechanism.  The merge function is injected (the CPU oracle), so this
+runs without a GPU; the HIP-backed default is exercised by the gpu-marked test at the bottom."""
+import math
+
+import pytest
+import torch
+
+from oracle import sttm_oracle as O
+from sttm_amd import monkey_patch_interface as MPI
+from sttm_amd import patch_hooks
+from sttm_amd.synth import synth_video
+
+
+def _prompt(T=4, H=14, W=14, C=32, n_sys=5, n_inst=7, seed=0):
+    vis = synth_video(T, C, H, W, seed=seed).permute(0, 2, 3, 1).reshape(1, T * H * W, C)
+    g = torch.Generator().manual_seed(seed + 1)
+    hs = torch.cat([torch.randn(1, n_sys, C, generator=g), vis, torch.randn(1, n_inst, C, generator=g)], dim=1)
+    return hs, n_sys, T * H * W
+
+
+def test_llava_hook_slices_merges_and_truncates_positions():
+    hs, start, length = _prompt()
+    pos = torch.arange(hs.shape[1]).unsqueeze(0)
+    out, pos2, idx = patch_hooks.quadtree_merge_llava(hs, pos, start, length, 4, O.get_quadtree_features, 0.85, 0.55, 1, False)
+    video = hs[0, start:start + length].reshape(4, 14, 14, -1).permute(0, 3, 1, 2)
+    f, _, t = O.get_quadtree_features(video, 0.85, 0.55, 1)
+    assert torch.equal(out[:, :start], hs[:, :start]) and torch.equal(out[:, start + f.shape[0]:], hs[:, start + length:])
+    assert torch.equal(out[0, start:start + f.shape[0]], f)
+    assert torch.equal(pos2, pos[:, :out.shape[1]])
+    assert torch.equal(idx, t[:, 0] * 196 + t[:, 1] * 14 + t[:, 2])
+    assert not out.data_ptr() == hs.data_ptr()
+
+
+def test_qwen2vl_hook_gathers_3d_positions():
+    T, H, W = 3, 10, 18
+    hs, start, length = _prompt(T, H, W, C=16)
+    S = hs.shape[1]
+    pos = torch.stack([torch.arange(S), torch.arange(S) * 2, torch.arange(S) * 3]).unsqueeze(1)      # [3, 1, S]
+    out, pos2, cache_pos, idx = patch_hooks.quadtree_merge_qwen2vl(hs, pos, start, length, T, H, W,
+                                                                   O.get_quadtree_features, 0.85, 0.6, 1, False)
+    n = idx.shape[0]
+    assert out.shape[1] == S - length + n and pos2.shape == (3, 1, out.shape[1])
+    assert torch.equal(pos2[:, :, :start], pos[:, :, :start])
+    assert torch.equal(pos2[:, :, start:start + n], pos[:, :, start:start + length][:, :, idx.long()])
+    assert torch.equal(pos2[:, :, start + n:], pos[:, :, start + length:])
+    assert torch.equal(cache_pos, torch.arange(out.shape[1], dtype=torch.int))
+
+
+def test_tome_hook():
+    hs, start, length = _prompt(T=3, C=16)
+    pos = torch.arange(hs.shape[1]).unsqueeze(0)
+    out, pos2, tok = patch_hooks.tome_merge(hs, pos, start, length, 3, O.get_tome_features, 0.5, "video")
+    assert out.shape[1] == hs.shape[1] - length + math.ceil(length * 0.5)
+    assert torch.equal(pos2, pos[:, :out.shape[1]])
+    assert tok.dtype == torch.int64
+
+
+def test_installer_names_and_errors():
+    for name in ("quadtree-abl-pos", "octree", "pyrd", "quadtree_vis", "dycoke", "dycoke-stage1", "nonsense"):
+        with pytest.raises(NotImplementedError):
+            MPI.replace_qwen2_by_sparse_attn(name)
+
+
+def test_patched_qwen2_forward_matches_manual_layers():
+    """Install the patch on a tiny random Qwen2Model and compare with running the layers by hand."""
+    transformers = pytest.importorskip("transformers")
+    from transformers import Qwen2Config
+    from transformers.models.qwen2.modeling_qwen2 import Qwen2Model
+    torch.manual_seed(0)
+    C = 32
+    cfg = Qwen2Config(vocab_size=64, hidden_size=C, intermediate_size=64, num_hidden_layers=3, num_attention_heads=4,
+                      num_key_value_heads=2, max_position_embeddings=4096, attn_implementation="sdpa")
+    model = Qwen2Model(cfg).eval()
+    hs, start, length = _prompt(T=4, C=C)
+    try:
+        MPI.replace_qwen2_by_sparse_attn("quadtree", sa_start_layer_idx=1, sa_tree_thresh=0.85, sa_tree_temporal_thresh=0.55,
+                                         sa_tree_root_level=1, unused_flag=123)
+        Qwen2Model.sttm_merge_fn = staticmethod(O.get_quadtree_features)          # inject the CPU oracle
+        assert Qwen2Model.sa_tree_thresh == 0.85 and Qwen2Model.sa_start_layer_idx == 1     # class attributes
+        model.image_token_start_index = torch.tensor(start)
+        model.image_token_length = torch.tensor(length)
+        model.num_frame = torch.tensor(4)
+        with torch.inference_mode():
+            out = model(inputs_embeds=hs, use_cache=False).last_hidden_state
+            # by hand
+            pos = torch.arange(hs.shape[1]).unsqueeze(0)
+            h = hs
+            pe = model.rotary_emb(h, pos)
+            h = model.layers[0](h, attention_mask=None, position_embeddings=pe, position_ids=pos)
+            h, pos, _ = patch_hooks.quadtree_merge_llava(h, pos, start, length, 4, O.get_quadtree_features, 0.85, 0.55, 1, False)
+            pe = model.rotary_emb(h, pos)
+            for layer in model.layers[1:]:
+                h = layer(h, attention_mask=None, position_embeddings=pe, position_ids=pos)
+            ref = model.norm(h)
+        assert out.shape == ref.shape and out.shape[1] < hs.shape[1]
+        assert torch.allclose(out, ref, atol=1e-5)
+    finally:
+        MPI.restore_qwen2()
+        if hasattr(Qwen2Model, "sttm_merge_fn"):
+            del Qwen2Model.sttm_merge_fn
+
+
+@pytest.mark.gpu
+def test_hook_on_gpu_uses_the_hip_path():
+    from sttm_amd import get_quadtree_features
+    dev = torch.device("cuda:0")
+    hs, start, length = _prompt(T=6, C=256)
+    pos = torch.arange(hs.shape[1]).unsqueeze(0)
+    out, pos2, idx = patch_hooks.quadtree_merge_llava(hs.to(dev), pos.to(dev), start, length, 6, get_quadtree_features,
+                                                      0.85, 0.55, 1, False)
+    ref, _, ridx = patch_hooks.quadtree_merge_llava(hs, pos, start, length, 6, O.get_quadtree_features, 0.85, 0.55, 1, False)
+    assert torch.equal(idx.cpu(), ridx) and float((out.cpu() - ref).abs().max()) <= 1e-5

@@ -1,0 +1,62 @@
+"""N > 1 path on CPU: two gloo ranks shard the videos, each merges its own (oracle as the compute stand-in),
+and the final gather reproduces the single-process result."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from sttm_amd.distributed import gather_counts, shard_videos
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_videos, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import sttm_oracle as O
+    from sttm_amd.synth import synth_video
+    ids = shard_videos(n_videos, world, rank)
+    counts = []
+    for v in ids:
+        x = synth_video(3, 16, 14, 14, seed=v)
+        f, _, _ = O.get_quadtree_features(x, 0.85, 0.55, 1)
+        counts.append(f.shape[0])
+    full = gather_counts(ids, counts, n_videos, torch.device("cpu"), dist)
+    dist.barrier()
+    torch.save(full, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_matches_single_process(tmp_path):
+    n_videos, world = 5, 2
+    mp.spawn(_worker, args=(world, _free_port(), n_videos, str(tmp_path)), nprocs=world, join=True)
+    from oracle import sttm_oracle as O
+    from sttm_amd.synth import synth_video
+    expect = torch.tensor([O.get_quadtree_features(synth_video(3, 16, 14, 14, seed=v), 0.85, 0.55, 1)[0].shape[0]
+                           for v in range(n_videos)], dtype=torch.int32)
+    for r in range(world):
+        got = torch.load(os.path.join(str(tmp_path), f"r{r}.pt"))
+        assert torch.equal(got, expect)
+
+
+def test_shard_videos_partitions():
+    for world in (1, 2, 4, 8):
+        owned = [shard_videos(19, world, r) for r in range(world)]
+        flat = sorted(i for o in owned for i in o)
+        assert flat == list(range(19))
+    costs = [128, 64, 180, 32, 128, 64, 16, 180]
+    owned = [shard_videos(len(costs), 3, r, costs) for r in range(3)]
+    assert sorted(i for o in owned for i in o) == list(range(len(costs)))
+    loads = [sum(costs[i] for i in o) for o in owned]
+    assert max(loads) - min(loads) <= max(costs)
