@@ -95,7 +95,7 @@ void root_extent_host(const sttm::LevelDims& g, int I, int J, int* ah, int* aw) 
 }
 
 struct Buffers {
-    char* S; uint32_t* meta; float* nrm2; int* rc_list;
+    char* S; uint32_t* meta; double* inrm; int* rc_list;
     int32_t *edges, *edge_cnt, *cand_cnt; unsigned long long* col_mask; int32_t *frame_cnt, *colscratch;
     int32_t *row2origin, *grp_cnt, *grp_off, *members;
 };
@@ -108,7 +108,7 @@ size_t carve_all(const Plan& p, int T, int C, int dtype, char* base, Buffers* b)
     Buffers& o = b ? *b : tmp;
     o.S = c.take<char>(N * C * elem_bytes(dtype));
     o.meta = c.take<uint32_t>(N * 4);
-    o.nrm2 = c.take<float>(N * 4);
+    o.inrm = c.take<double>(N * 8);
     o.rc_list = c.take<int>((size_t)T * p.R * p.rc_stride * 4);
     o.edges = c.take<int32_t>(nfr * p.ecap * 8);
     o.edge_cnt = c.take<int32_t>(nfr * 4);
@@ -144,7 +144,9 @@ int make_plan(int T, int H, int W, int C, int dtype, int root_level, Plan* p) {
 
 int pick_vec(int C, int dtype, const void* x, int64_t sT, int64_t sH, int64_t sW, int* nt) {
     const int eb = elem_bytes(dtype);
-    const int cands_f32[] = {4, 2, 1}, cands_16[] = {8, 4, 2};
+    // 16-bit inputs: 4-wide packs (8 B/lane, still full-line coalescing) keep the spatial kernel spill-free;
+    // 8-wide packs only when the row would not fit one workgroup otherwise (C > 4096)
+    const int cands_f32[] = {4, 2, 1}, cands_16[] = {4, 8, 2};
     const int* cands = dtype == STTM_F32 ? cands_f32 : cands_16;
     for (int k = 0; k < 3; ++k) {
         const int v = cands[k];
@@ -220,12 +222,24 @@ int sttm_quadtree_merge(const void* x, int64_t stride_t, int64_t stride_c, int64
     sa.T = T; sa.H = H; sa.W = W; sa.C = C;
     sa.dims = p.dims;
     sa.threshold = threshold;
+    {
+        // `sim_f32 >= threshold_f32` <=> `sim >= lo`: lo = midpoint below the fp32 threshold (exclusive when the
+        // tie would round down to the predecessor, i.e. when the threshold's mantissa is odd)
+        const float thr = threshold;
+        const float pred = nextafterf(thr, -INFINITY);
+        double lo = 0.5 * ((double)pred + (double)thr);
+        uint32_t bits; memcpy(&bits, &thr, 4);
+        if (bits & 1u) lo = nextafter(lo, (double)INFINITY);
+        sa.thr_lo_sq = lo * fabs(lo);
+    }
     sa.sum_mode = weighted_avg ? 1 : 0;
-    sa.S = b.S; sa.meta = b.meta; sa.nrm2 = b.nrm2; sa.rc_list = b.rc_list;
+    // dense [T*H*W, C] input: the rows of 1x1 nodes are read from x by the later kernels instead of being copied to S
+    const bool dense = stride_w == C && stride_h == (int64_t)W * C && stride_t == (int64_t)H * W * C;
+    sa.leaves_in_x = dense ? 1 : 0;
+    sa.S = b.S; sa.meta = b.meta; sa.inrm = b.inrm; sa.rc_list = b.rc_list;
     sa.rc_stride = p.rc_stride;
     sa.counts = counts;
     sa.frame_cnt = b.frame_cnt;
-    sa.dbg_sims = nullptr;
 
     sttm::TemporalArgs ta;
     memset(&ta, 0, sizeof(ta));
@@ -239,7 +253,7 @@ int sttm_quadtree_merge(const void* x, int64_t stride_t, int64_t stride_c, int64
         const char* fg = getenv("STTM_FORCE_GMEM_LABELS");
         ta.force_gmem = (fg && fg[0] == '1') ? 1 : 0;
     }
-    ta.S = b.S; ta.meta = b.meta; ta.nrm2 = b.nrm2; ta.rc_list = b.rc_list; ta.rc_stride = p.rc_stride;
+    ta.S = b.S; ta.xrows = dense ? x : nullptr; ta.meta = b.meta; ta.inrm = b.inrm; ta.rc_list = b.rc_list; ta.rc_stride = p.rc_stride;
     ta.edges = b.edges; ta.ecap = p.ecap; ta.edge_cnt = b.edge_cnt; ta.cand_cnt = b.cand_cnt;
     ta.col_mask = b.col_mask; ta.frame_cnt = b.frame_cnt; ta.colscratch = b.colscratch;
     ta.row2origin = b.row2origin; ta.grp_cnt = b.grp_cnt; ta.grp_off = b.grp_off; ta.members = b.members;

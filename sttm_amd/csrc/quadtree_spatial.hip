@@ -190,50 +190,64 @@ __device__ __forceinline__ void block_stats(const BlockRegs<T, VEC>& r, const Bl
             part[id] = tot;
         }
     } else {
-        float s[41];
+        // two mids at a time (18 partials live instead of 41: keeps the kernel at 4 workgroups per CU)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int h = 0; h < 2; ++h) {
+            float s[18];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                s[k * 4 + q] = dot_pack(r.leaf[k][q], r.leaf[k][q]);
-                s[21 + k * 4 + q] = b.v2[k][q] ? dot_pack(r.mid[k], r.leaf[k][q]) : dot_pack(r.mid[k], alias[lvl + 2]);
+            for (int kk = 0; kk < 2; ++kk) {
+                const int k = 2 * h + kk;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    s[kk * 9 + q] = dot_pack(r.leaf[k][q], r.leaf[k][q]);
+                    s[kk * 9 + 5 + q] = b.v2[k][q] ? dot_pack(r.mid[k], r.leaf[k][q]) : dot_pack(r.mid[k], alias[lvl + 2]);
+                }
+                s[kk * 9 + 4] = dot_pack(r.mid[k], r.mid[k]);
             }
-            s[16 + k] = dot_pack(r.mid[k], r.mid[k]);
-            s[37 + k] = b.v1[k] ? dot_pack(r.top, r.mid[k]) : dot_pack(r.top, alias[lvl + 1]);
+            const float tot = wave_reduce_many<18>(s, lane);
+            bool ok;
+            const int idx = wave_reduce_slot<18>(lane, ok);
+            if (ok && valid) {
+                const int k = 2 * h + idx / 9, e = idx % 9;
+                const int mid = 4 * tn + 1 + k;
+                int id;
+                if (e < 4) id = 4 * mid + 1 + e;
+                else if (e == 4) id = mid;
+                else id = TC::dot_id(mid, e - 5);
+                part[id] = tot;
+            }
         }
-        s[20] = dot_pack(r.top, r.top);
-        const float tot = wave_reduce_many<41>(s, lane);
+        float s[5];
+        s[0] = dot_pack(r.top, r.top);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[1 + k] = b.v1[k] ? dot_pack(r.top, r.mid[k]) : dot_pack(r.top, alias[lvl + 1]);
+        const float tot = wave_reduce_many<5>(s, lane);
         bool ok;
-        const int idx = wave_reduce_slot<41>(lane, ok);
-        if (ok && valid) {
-            int id;
-            if (idx < 16) id = 4 * (4 * tn + 1 + (idx >> 2)) + 1 + (idx & 3);
-            else if (idx < 20) id = 4 * tn + 1 + (idx - 16);
-            else if (idx == 20) id = tn;
-            else if (idx < 37) id = TC::dot_id(4 * tn + 1 + ((idx - 21) >> 2), (idx - 21) & 3);
-            else id = TC::dot_id(tn, idx - 37);
-            part[id] = tot;
-        }
+        const int idx = wave_reduce_slot<5>(lane, ok);
+        if (ok && valid) part[idx == 0 ? tn : TC::dot_id(tn, idx - 1)] = tot;
     }
 }
 
 // store the emitted nodes of a block from registers; orow[node] = destination row in S or -1
 template <typename T, int VEC, int BL>
 __device__ __forceinline__ void block_store(const BlockRegs<T, VEC>& r, int tn, const int* orow, void* S, int C,
-                                            const SpatialCtx& cx) {
+                                            const SpatialCtx& cx, bool skip_leaves) {
     if (!cx.active) return;
-    {
+    if (BL > 1 || !skip_leaves) {
         const int row = orow[tn];
         if (row >= 0) store_pack<T, VEC>(S, (int64_t)row * C + cx.c0, r.top);
     }
     if constexpr (BL >= 2) {
+        if (BL > 2 || !skip_leaves) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int row = orow[4 * tn + 1 + k];
-            if (row >= 0) store_pack<T, VEC>(S, (int64_t)row * C + cx.c0, r.mid[k]);
+            for (int k = 0; k < 4; ++k) {
+                const int row = orow[4 * tn + 1 + k];
+                if (row >= 0) store_pack<T, VEC>(S, (int64_t)row * C + cx.c0, r.mid[k]);
+            }
         }
     }
     if constexpr (BL == 3) {
+        if (skip_leaves) return;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -250,6 +264,7 @@ struct NodeLoc {
     bool valid;
     int path[kMaxLevels];     // node ids from the root (path[0] = 0) down to the node itself
     int slot[kMaxLevels];     // slot[d] = child slot taken to reach depth d (slot[0] unused)
+    int pi[kMaxLevels], pj[kMaxLevels];   // cell coordinates along the path
 };
 __device__ __forceinline__ NodeLoc locate(const LevelDims& g, int I, int J, int n) {
     NodeLoc L;
@@ -258,7 +273,7 @@ __device__ __forceinline__ NodeLoc locate(const LevelDims& g, int I, int J, int 
     L.depth = d;
     const int rel = n - depth_base(d);
     L.i = I; L.j = J; L.valid = true;
-    L.path[0] = 0;
+    L.path[0] = 0; L.pi[0] = I; L.pj[0] = J;
     int id = 0;
     for (int s = 1; s <= d; ++s) {
         const int k = (rel >> (2 * (d - s))) & 3;
@@ -270,30 +285,36 @@ __device__ __forceinline__ NodeLoc locate(const LevelDims& g, int I, int J, int 
         L.path[s] = id;
         L.slot[s] = k;
         if (!L.valid) { L.i = 0; L.j = 0; }
+        L.pi[s] = L.i; L.pj[s] = L.j;
     }
     return L;
 }
 
-__device__ __forceinline__ float cosine_from_sums(float dot, float n2a, float n2b) {
-    // F.cosine_similarity: sum( (a / max(|a|, eps)) * (b / max(|b|, eps)) ), eps = 1e-8; evaluated in
-    // double from the fp32 sums and rounded once to fp32 for the comparison.
-    const double na = fmax(sqrt((double)n2a), 1e-8);
-    const double nb = fmax(sqrt((double)n2b), 1e-8);
-    return (float)((double)dot / (na * nb));
+// F.cosine_similarity(p, c) = sum((p / max(|p|, eps)) * (c / max(|c|, eps))), eps = 1e-8, then `>= threshold` on
+// the fp32 value (quadtree_builder.py:61-68).  With the fp32 sums dot, |p|^2, |c|^2 the test
+//     fp32(dot / (max(|p|,eps) * max(|c|,eps))) >= thr
+// is evaluated without sqrt/div: rounding to fp32 is monotonic, so it equals  sim >= lo  where lo is the smallest
+// real that rounds to >= thr (`thr_lo`, computed on the host in double), and  sim >= lo  <=>
+// dot*|dot| >= lo*|lo| * max(|p|^2, eps^2) * max(|c|^2, eps^2)   (the product of two fp32 values is exact in double).
+__device__ __forceinline__ bool cosine_at_least(float dot, float n2a, float n2b, double lo_sq_signed) {
+    const double a = fmax((double)n2a, 1e-16), b = fmax((double)n2b, 1e-16);
+    const double d = (double)dot;
+    return d * fabs(d) >= lo_sq_signed * (a * b);
 }
 
 template <typename T, int VEC, int BL, int UL, int MAXNT>
-__global__ void __launch_bounds__(MAXNT) k_spatial(SpatialArgs a) {
+__global__ void __launch_bounds__(MAXNT, 4) k_spatial(SpatialArgs a) {
     constexpr int D = BL + UL;
     using TC = TreeConst<D>;
     constexpr int NSTAT = TC::NSTAT;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int nwave = blockDim.x / kWave;
-    float* part = reinterpret_cast<float*>(smem_raw);            // [nwave][NSTAT]
+    double* inrm_l = reinterpret_cast<double*>(smem_raw);         // [NNODE] 1 / (|node| + 1e-8)
+    float* part = reinterpret_cast<float*>(inrm_l + TC::NNODE);   // [nwave][NSTAT]
     float* stat = part + nwave * NSTAT;                           // [NSTAT]
     int* stop = reinterpret_cast<int*>(stat + NSTAT);             // [NPAR] (>= 1)
     int* orow = stop + (TC::NPAR > 0 ? TC::NPAR : 1);             // [NNODE]
-    int* lcount = orow + TC::NNODE;                               // [1]
+    int* lcount = orow + TC::NNODE;                               // [1] (+1 pad)
 
     const LevelDims& g = a.dims;
     const int R = g.h[0] * g.w[0];
@@ -318,6 +339,7 @@ __global__ void __launch_bounds__(MAXNT) k_spatial(SpatialArgs a) {
 
     for (int s = tid; s < nwave * NSTAT; s += blockDim.x) part[s] = 0.f;
     for (int s = tid; s < TC::NNODE; s += blockDim.x) orow[s] = -1;
+    for (int s = tid; s < TC::NPAR; s += blockDim.x) stop[s] = 1;
     if (tid == 0) *lcount = 0;
 
     // alias features: cell (0,0) of level m is needed when some parent of level m-1 inside this root cell
@@ -422,67 +444,61 @@ __global__ void __launch_bounds__(MAXNT) k_spatial(SpatialArgs a) {
     }
     __syncthreads();
 
-    // ---- phase 2: cross-wave sum in a fixed order ------------------------------------------------------
-    for (int s = tid; s < NSTAT; s += blockDim.x) {
-        float acc = 0.f;
-        for (int w = 0; w < nwave; ++w) acc += part[w * NSTAT + s];
-        stat[s] = acc;
-    }
-    __syncthreads();
-
-    // ---- phase 3: stop flag of every parent node (quadtree_builder.py:61-68) -----------------------------
-    for (int p = tid; p < TC::NPAR; p += blockDim.x) {
-        const NodeLoc L = locate(g, I, J, p);
-        int st = 0;
-        if (L.valid) {
-            const CellGeo c = cell_children(g, L.depth, L.i, L.j);
-            const float n2p = stat[p];
-            st = 1;
-            for (int k = 0; k < 4; ++k) {
-                const bool vk = (k >> 1) < c.rc && (k & 1) < c.cc;
-                const float n2c = vk ? stat[4 * p + 1 + k] : stat[TC::alias_id(L.depth + 1)];
-                const float sim = cosine_from_sums(stat[TC::dot_id(p, k)], n2p, n2c);
-                if (!(sim >= a.threshold)) st = 0;
-                if (a.dbg_sims) a.dbg_sims[((int64_t)blockIdx.x * (TC::NPAR > 0 ? TC::NPAR : 1) + p) * 4 + k] = sim;
-            }
-        }
-        stop[p] = st;
-    }
-    __syncthreads();
-
-    // ---- phase 4: emission, one thread per leaf position of the root cell ---------------------------------
-    // The leaf-level node n learns its first stopped ancestor a (or itself).  The node a is emitted; the
-    // leaf that is a's top-left descendant (all slots below a are 0) is a's origin and writes a's metadata.
     const int HW = a.H * a.W;
     int* rc_list = a.rc_list + (int64_t)blockIdx.x * a.rc_stride;
-    for (int q = tid; q < TC::NLEAF; q += blockDim.x) {
-        const int n = depth_base(D - 1) + q;
-        const NodeLoc L = locate(g, I, J, n);
-        if (!L.valid) continue;
-        int da = D - 1;
-        for (int d = 0; d < D - 1; ++d) {
-            if (stop[L.path[d]]) { da = d; break; }
-        }
+    // fixed-order cross-wave sum of one statistic: identical bits in whichever thread evaluates it
+    auto stat_of = [&](int id) { float acc = 0.f; for (int w = 0; w < nwave; ++w) acc += part[w * NSTAT + id]; return acc; };
+    // emission of one leaf position (shared by both paths): `da` = depth of the first stopped ancestor (or D-1)
+    auto emit_leaf = [&](const NodeLoc& L, int da) {
         bool origin = true;
         for (int d = da + 1; d <= D - 1; ++d) origin = origin && (L.slot[d] == 0);
         const int leaf_row = t * HW + L.i * a.W + L.j;
-        if (!origin) {
-            a.meta[leaf_row] = 0u;
-            continue;
-        }
+        if (!origin) { a.meta[leaf_row] = 0u; return; }
         // box of the emitted ancestor: top-left is this leaf; bottom-right follows last children down
-        const NodeLoc A = locate(g, I, J, L.path[da]);
-        int hi_i = A.i, hi_j = A.j;
+        int hi_i = L.pi[da], hi_j = L.pj[da];
         for (int m = da; m < D - 1; ++m) {
             hi_i = child_start(hi_i, g.h[m + 1]) + child_count(hi_i, g.h[m + 1]) - 1;
             hi_j = child_start(hi_j, g.w[m + 1]) + child_count(hi_j, g.w[m + 1]) - 1;
         }
         const int y2 = hi_i + 1, x2 = hi_j + 1;
         a.meta[leaf_row] = ((uint32_t)y2 << 16) | (uint32_t)x2;
-        a.nrm2[leaf_row] = stat[L.path[da]];
+        a.inrm[leaf_row] = inrm_l[L.path[da]];
         orow[L.path[da]] = leaf_row;
         const int pos = atomicAdd(lcount, 1);
         rc_list[1 + pos] = (L.i << 24) | (L.j << 16) | (y2 << 8) | x2;
+    };
+
+    // ---- phase 2: cross-wave sum in a fixed order ------------------------------------------------------------
+    for (int s2 = tid; s2 < NSTAT; s2 += blockDim.x) stat[s2] = stat_of(s2);
+    __syncthreads();
+    // ---- phase 3: every (parent, slot) cosine test and every node's inverse norm, one thread each, spread over
+    //      the waves so the four SIMDs work side by side -----------------------------------------------------------
+    for (int base = 0; base < 4 * TC::NPAR + TC::NNODE; base += blockDim.x) {
+        const int e = base + (tid & 63) * nwave + (tid >> 6);  // lane-major: consecutive items land on different waves
+        if (e < 4 * TC::NPAR) {
+            const int p = e >> 2, k = e & 3;
+            const NodeLoc L = locate(g, I, J, p);
+            if (L.valid) {
+                const CellGeo c = cell_children(g, L.depth, L.i, L.j);
+                const bool vk = (k >> 1) < c.rc && (k & 1) < c.cc;
+                const float n2c = vk ? stat[4 * p + 1 + k] : stat[TC::alias_id(L.depth + 1)];
+                if (!cosine_at_least(stat[TC::dot_id(p, k)], stat[p], n2c, a.thr_lo_sq)) stop[p] = 0;
+            }
+        } else if (e < 4 * TC::NPAR + TC::NNODE) {
+            const int n = e - 4 * TC::NPAR;
+            inrm_l[n] = 1.0 / (sqrt((double)stat[n]) + 1e-8);     // temporal stage: x / (|x| + 1e-8)
+        }
+    }
+    __syncthreads();
+    // ---- phase 4: emission, one thread per leaf position of the root cell -------------------------------------
+    for (int q = tid; q < TC::NLEAF; q += blockDim.x) {
+        const NodeLoc L = locate(g, I, J, depth_base(D - 1) + q);
+        if (!L.valid) continue;
+        int da = D - 1;
+        for (int d = 0; d < D - 1; ++d) {
+            if (stop[L.path[d]]) { da = d; break; }
+        }
+        emit_leaf(L, da);
     }
     __syncthreads();
     if (tid == 0) {
@@ -493,7 +509,7 @@ __global__ void __launch_bounds__(MAXNT) k_spatial(SpatialArgs a) {
 
     // ---- phase 5: store the emitted features ----------------------------------------------------------------
     if constexpr (UL == 0) {
-        block_store<T, VEC, BL>(regs, 0, orow, a.S, a.C, cx);
+        block_store<T, VEC, BL>(regs, 0, orow, a.S, a.C, cx, a.leaves_in_x != 0);
     } else if constexpr (UL == 1) {
         if (cx.active && orow[0] >= 0) store_pack<T, VEC>(a.S, (int64_t)orow[0] * a.C + cx.c0, root);
         if (!stop[0]) {
@@ -509,7 +525,7 @@ __global__ void __launch_bounds__(MAXNT) k_spatial(SpatialArgs a) {
                     const int bi = c0.rs + (k >> 1), bj = c0.cs + (k & 1);
                     block_geometry<BL>(g, 1, bi, bj, true, bg);
                     load_and_pool_block<T, VEC, BL>(cx, t, bi, bj, true, bg, regs);
-                    block_store<T, VEC, BL>(regs, tn, orow, a.S, a.C, cx);
+                    block_store<T, VEC, BL>(regs, tn, orow, a.S, a.C, cx, a.leaves_in_x != 0);
                 }
             }
         }
@@ -535,7 +551,7 @@ __global__ void __launch_bounds__(MAXNT) k_spatial(SpatialArgs a) {
                     const int bi = c1.rs + (k1 >> 1), bj = c1.cs + (k1 & 1);
                     block_geometry<BL>(g, 2, bi, bj, true, bg);
                     load_and_pool_block<T, VEC, BL>(cx, t, bi, bj, true, bg, regs);
-                    block_store<T, VEC, BL>(regs, 4 * un + 1 + k1, orow, a.S, a.C, cx);
+                    block_store<T, VEC, BL>(regs, 4 * un + 1 + k1, orow, a.S, a.C, cx, a.leaves_in_x != 0);
                 }
             }
         }
@@ -550,7 +566,7 @@ static hipError_t launch_bl_ul(const SpatialArgs& a, int grid, int nt, hipStream
     constexpr int D = BL + UL;
     using TC = TreeConst<D>;
     const int nwave = nt / kWave;
-    const size_t smem = sizeof(float) * ((size_t)nwave * TC::NSTAT + TC::NSTAT) +
+    const size_t smem = sizeof(double) * TC::NNODE + sizeof(float) * ((size_t)nwave * TC::NSTAT + TC::NSTAT) +
                         sizeof(int) * ((TC::NPAR > 0 ? TC::NPAR : 1) + TC::NNODE + 4);
     if (nt <= 256) hipLaunchKernelGGL((k_spatial<T, VEC, BL, UL, 256>), dim3(grid), dim3(nt), smem, stream, a);
     else if (nt <= 512) hipLaunchKernelGGL((k_spatial<T, VEC, BL, UL, 512>), dim3(grid), dim3(nt), smem, stream, a);

@@ -11,16 +11,17 @@ struct SpatialArgs {
     int T, H, W, C;
     LevelDims dims;
     float threshold;
+    double thr_lo_sq;         // lo*|lo| with lo = smallest real that rounds (fp32, RNE) to >= threshold
     int sum_mode;             // weighted_avg: sum-pool pyramid
+    int leaves_in_x;          // x is a dense [T*H*W, C] matrix: 1x1 nodes are NOT copied to S (consumers read x)
     // outputs
     void* S;                  // [T*H*W, C] node features at their origin rows (input dtype)
     uint32_t* meta;           // [T*H*W] 0 = no node starts here, else (y2 << 16) | x2
-    float* nrm2;              // [T*H*W] squared L2 norm of the node feature (fp32)
+    double* inrm;             // [T*H*W] 1 / (|node feature| + 1e-8) for the temporal cosine
     int* rc_list;             // [T*R][rc_stride]: count, then packed (y1<<24 | x1<<16 | y2<<8 | x2)
     int rc_stride;
     int32_t* counts;          // STTM_CNT_* slots (zeroed here, filled by the later kernels)
     int32_t* frame_cnt;       // [T] zeroed here for the label kernels
-    float* dbg_sims;          // optional [T*R][NPAR][4] similarities (debug / tests), may be null
 };
 hipError_t launch_spatial(const SpatialArgs& a, int dtype, int vec, int nt, hipStream_t stream);
 
@@ -33,8 +34,9 @@ struct TemporalArgs {
     int max_slots;            // T * (largest root-cell area in leaves)
     int force_gmem;           // debug/test: run the label kernels on the global-memory path
     const void* S;
+    const void* xrows;        // non-null: x as a dense [T*H*W, C] matrix; rows of 1x1 nodes live there, not in S
     const uint32_t* meta;
-    const float* nrm2;
+    const double* inrm;
     const int* rc_list;
     int rc_stride;
     // scratch

@@ -69,18 +69,25 @@ __global__ void __launch_bounds__(256) k_pairs(TemporalArgs a) {
         const unsigned b = (unsigned)L[1 + i];
         return frame * HW + (int)(b >> 24) * a.W + (int)((b >> 16) & 255);
     };
+    auto src_of = [&](const int* L, int i) -> const void* {      // 1x1 nodes were not copied out of x
+        const unsigned b = (unsigned)L[1 + i];
+        const bool leaf = ((b >> 8) & 255) - (b >> 24) == 1 && (b & 255) - ((b >> 16) & 255) == 1;
+        return (leaf && a.xrows) ? a.xrows : a.S;
+    };
     for (int c = wave; c < nc; c += 2 * nwave) {
         const int c2 = c + nwave;
         const bool two = c2 < nc;
         const int k0 = cand[c], k1 = two ? cand[c2] : k0;
         const int rowA0 = row_of(LA, k0 >> 16, t), rowB0 = row_of(LB, k0 & 0xffff, t + 1);
         const int rowA1 = row_of(LA, k1 >> 16, t), rowB1 = row_of(LB, k1 & 0xffff, t + 1);
+        const void* sA0 = src_of(LA, k0 >> 16); const void* sB0 = src_of(LB, k0 & 0xffff);
+        const void* sA1 = src_of(LA, k1 >> 16); const void* sB1 = src_of(LB, k1 & 0xffff);
         float d0 = 0.f, d1 = 0.f;
         for (int c0 = lane * VEC; c0 < a.C; c0 += 64 * VEC) {
-            const Pack<T, VEC> pa0 = load_pack<T, VEC>(a.S, (int64_t)rowA0 * a.C + c0);
-            const Pack<T, VEC> pb0 = load_pack<T, VEC>(a.S, (int64_t)rowB0 * a.C + c0);
-            const Pack<T, VEC> pa1 = load_pack<T, VEC>(a.S, (int64_t)rowA1 * a.C + c0);
-            const Pack<T, VEC> pb1 = load_pack<T, VEC>(a.S, (int64_t)rowB1 * a.C + c0);
+            const Pack<T, VEC> pa0 = load_pack<T, VEC>(sA0, (int64_t)rowA0 * a.C + c0);
+            const Pack<T, VEC> pb0 = load_pack<T, VEC>(sB0, (int64_t)rowB0 * a.C + c0);
+            const Pack<T, VEC> pa1 = load_pack<T, VEC>(sA1, (int64_t)rowA1 * a.C + c0);
+            const Pack<T, VEC> pb1 = load_pack<T, VEC>(sB1, (int64_t)rowB1 * a.C + c0);
             d0 += dot_pack(pa0, pb0);
             d1 += dot_pack(pa1, pb1);
         }
@@ -89,10 +96,9 @@ __global__ void __launch_bounds__(256) k_pairs(TemporalArgs a) {
         if (lane < 2 && (lane == 0 || two)) {
             const int rowA = lane ? rowA1 : rowA0, rowB = lane ? rowB1 : rowB0;
             const float dot = lane ? d1 : d0;
-            // x / (|x| + 1e-8) on both sides (quadtree_temporal_merger.py:62-63), evaluated in double
-            const double na = sqrt((double)a.nrm2[rowA]) + 1e-8;
-            const double nb = sqrt((double)a.nrm2[rowB]) + 1e-8;
-            const float sim = (float)((double)dot / (na * nb));
+            // x / (|x| + 1e-8) on both sides (quadtree_temporal_merger.py:62-63); the spatial kernel stored
+            // 1 / (|x| + 1e-8) in double
+            const float sim = (float)((double)dot * a.inrm[rowA] * a.inrm[rowB]);
             if (sim >= a.temporal_thresh) {
                 const int e = atomicAdd(&nkept, 1);
                 my_edges[2 * e] = rowA;
@@ -561,10 +567,15 @@ __global__ void __launch_bounds__(256) k_group_mean(TemporalArgs a) {
         for (int d = 32; d >= 1; d >>= 1) patches += __shfl_xor(patches, d, 64);
         const bool divide = a.weighted_avg || cnt > 1;
         const float den = round_to<T>(a.weighted_avg ? (float)patches : (float)cnt);
+        auto src_of = [&](int r) -> const void* {                 // 1x1 nodes were not copied out of x
+            return (a.xrows && box_area(a.meta[r], r, HW, a.W) == 1) ? a.xrows : a.S;
+        };
+        const void* s0 = src_of(origin);
         for (int c0 = lane * VEC; c0 < a.C; c0 += 64 * VEC) {
-            Pack<T, VEC> acc = load_pack<T, VEC>(a.S, (int64_t)origin * a.C + c0);
+            Pack<T, VEC> acc = load_pack<T, VEC>(s0, (int64_t)origin * a.C + c0);
             for (int m = 1; m < cnt; ++m) {
-                const Pack<T, VEC> p = load_pack<T, VEC>(a.S, (int64_t)a.members[off + m] * a.C + c0);
+                const int mr = a.members[off + m];
+                const Pack<T, VEC> p = load_pack<T, VEC>(src_of(mr), (int64_t)mr * a.C + c0);
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) acc.set(e, acc.get(e) + p.get(e));
             }
