@@ -97,7 +97,7 @@ void root_extent_host(const sttm::LevelDims& g, int I, int J, int* ah, int* aw) 
 struct Buffers {
     char* S; uint32_t* meta; double* inrm; int* rc_list;
     int32_t *edges, *edge_cnt, *cand_cnt; unsigned long long* col_mask; int32_t *frame_cnt, *colscratch;
-    int32_t *row2origin, *grp_cnt, *grp_off, *members;
+    int4* row_info; int32_t *grp_np, *grp_cnt, *grp_off, *members;
 };
 
 size_t carve_all(const Plan& p, int T, int C, int dtype, char* base, Buffers* b) {
@@ -116,7 +116,8 @@ size_t carve_all(const Plan& p, int T, int C, int dtype, char* base, Buffers* b)
     o.col_mask = c.take<unsigned long long>((size_t)p.R * 8);
     o.frame_cnt = c.take<int32_t>((size_t)T * 4);
     o.colscratch = c.take<int32_t>(N * 16);
-    o.row2origin = c.take<int32_t>(N * 4);
+    o.row_info = c.take<int4>(N * 16);
+    o.grp_np = c.take<int32_t>(N * 4);
     o.grp_cnt = c.take<int32_t>(N * 4);
     o.grp_off = c.take<int32_t>(N * 4);
     o.members = c.take<int32_t>(N * 4);
@@ -256,7 +257,7 @@ int sttm_quadtree_merge(const void* x, int64_t stride_t, int64_t stride_c, int64
     ta.S = b.S; ta.xrows = dense ? x : nullptr; ta.meta = b.meta; ta.inrm = b.inrm; ta.rc_list = b.rc_list; ta.rc_stride = p.rc_stride;
     ta.edges = b.edges; ta.ecap = p.ecap; ta.edge_cnt = b.edge_cnt; ta.cand_cnt = b.cand_cnt;
     ta.col_mask = b.col_mask; ta.frame_cnt = b.frame_cnt; ta.colscratch = b.colscratch;
-    ta.row2origin = b.row2origin; ta.grp_cnt = b.grp_cnt; ta.grp_off = b.grp_off; ta.members = b.members;
+    ta.row_info = b.row_info; ta.grp_np = b.grp_np; ta.grp_cnt = b.grp_cnt; ta.grp_off = b.grp_off; ta.members = b.members;
     ta.counts = counts;
     ta.feat_out = feat_out; ta.npatch_out = npatch_out; ta.tlbr_out = tlbr_out;
 

@@ -47,10 +47,11 @@ struct TemporalArgs {
     unsigned long long* col_mask;   // [R] per-column idempotency history (bit k = idempotent after iteration k+1)
     int32_t* frame_cnt;       // [T] survivors per frame (zeroed by the spatial kernel)
     int32_t* colscratch;      // [4*T*H*W] label arrays of columns that do not fit LDS
-    int32_t* row2origin;      // [T*H*W]
+    int4* row_info;           // [T*H*W] per output row: origin | leaf bit, member offset, member count, patches
+    int32_t* grp_np;          // [T*H*W] by origin row: patches covered by the group
     int32_t* grp_cnt;         // [T*H*W] by origin row; 0 = not a survivor
     int32_t* grp_off;         // [T*H*W] by origin row
-    int32_t* members;         // [T*H*W] origin rows, grouped, ascending inside a group
+    int32_t* members;         // [T*H*W] origin rows (| leaf bit), grouped, ascending inside a group
     int32_t* counts;
     // outputs
     void* feat_out;

@@ -202,6 +202,7 @@ __device__ __forceinline__ int box_area(uint32_t meta, int row, int HW, int W) {
 }
 
 constexpr int kColThreads = 1024;
+constexpr int kLeafBit = (int)0x80000000;     // members / row_info: the row is a 1x1 node (its feature lives in x, not S)
 constexpr int kMaxProbeIters = 62;
 
 // Column arrays live in LDS (GMEM == false) or, for columns too large for the 160 KB LDS, in a per-column
@@ -335,6 +336,7 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
         }
         // from here: rep = final labels; rep2, the edge array and `mem` are free
         int* gcnt = rep2;
+        const int HW = a.H * a.W;
         for (int i = tid; i < slots; i += nt) cst<GMEM>(gcnt + i, 0);
         __syncthreads();
         int nodes = 0;
@@ -393,14 +395,25 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
             const int n = cld<GMEM>(gcnt + i);
             if (n == 0) continue;
             const int o = cld<GMEM>(aux + i) - n;          // the cursor ended at offset + n
-            if (n == 1) { out[o] = slot_to_row(a, col, cld<GMEM>(mem + o)); continue; }
+            const int self_row = slot_to_row(a, col, i);
+            if (n == 1) {
+                const int ar = box_area(a.meta[self_row], self_row, HW, a.W);
+                out[o] = self_row | (ar == 1 ? kLeafBit : 0);
+                a.grp_np[self_row] = ar;
+                continue;
+            }
             if (n > kSmall) { flags[0] = 1; continue; }
+            int patches = 0;
             for (int m = 0; m < n; ++m) {
                 const int v = cld<GMEM>(mem + o + m);
                 int rk = 0;
                 for (int j = 0; j < n; ++j) rk += cld<GMEM>(mem + o + j) < v ? 1 : 0;
-                out[o + rk] = slot_to_row(a, col, v);
+                const int vr = slot_to_row(a, col, v);
+                const int ar = box_area(a.meta[vr], vr, HW, a.W);
+                patches += ar;
+                out[o + rk] = vr | (ar == 1 ? kLeafBit : 0);
             }
+            a.grp_np[self_row] = patches;
         }
         __syncthreads();
         if (flags[0]) {
@@ -408,12 +421,19 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
                 const int n = cld<GMEM>(gcnt + i);
                 if (n <= kSmall) continue;
                 const int o = cld<GMEM>(aux + i) - n;
+                int patches = 0;
                 for (int m = lane; m < n; m += 64) {
                     const int v = cld<GMEM>(mem + o + m);
                     int rk = 0;
                     for (int j = 0; j < n; ++j) rk += cld<GMEM>(mem + o + j) < v ? 1 : 0;
-                    out[o + rk] = slot_to_row(a, col, v);
+                    const int vr = slot_to_row(a, col, v);
+                    const int ar = box_area(a.meta[vr], vr, HW, a.W);
+                    patches += ar;
+                    out[o + rk] = vr | (ar == 1 ? kLeafBit : 0);
                 }
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) patches += __shfl_xor(patches, d, 64);
+                if (lane == 0) a.grp_np[slot_to_row(a, col, i)] = patches;
             }
         }
         // bookkeeping counters: one atomic per column and slot
@@ -475,7 +495,20 @@ __global__ void __launch_bounds__(256) k_rank(TemporalArgs a) {
     int tot = 0;
     int off = base + block_exclusive_scan(mine, wsum, &tot);
     for (int p = lo; p < hi; ++p) {
-        if (a.grp_cnt[t * HW + p] > 0) a.row2origin[off++] = t * HW + p;
+        const int origin = t * HW + p;
+        const int cnt = a.grp_cnt[origin];
+        if (cnt > 0) {
+            const uint32_t meta = a.meta[origin];
+            const int np = a.grp_np[origin];
+            const int y1 = p / a.W, x1 = p - y1 * a.W;
+            const int y2 = (int)(meta >> 16), x2 = (int)(meta & 0xffff);
+            const bool leaf = (y2 - y1) == 1 && (x2 - x1) == 1;
+            a.row_info[off] = make_int4(origin | (leaf ? kLeafBit : 0), a.grp_off[origin], cnt, np);
+            a.npatch_out[off] = np;
+            int32_t* o = a.tlbr_out + (int64_t)off * 5;
+            o[0] = t; o[1] = y1; o[2] = x1; o[3] = y2; o[4] = x2;
+            ++off;
+        }
     }
     if (t == a.T - 1 && tid == 0) a.counts[STTM_CNT_OUT] = base + tot;
 }
@@ -554,28 +587,18 @@ template <typename T, int VEC>
 __global__ void __launch_bounds__(256) k_group_mean(TemporalArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     const int n_out = a.counts[STTM_CNT_OUT];
-    const int HW = a.H * a.W;
     for (int row = blockIdx.x * nwave + wave; row < n_out; row += gridDim.x * nwave) {
-        const int origin = a.row2origin[row];
-        const int off = a.grp_off[origin], cnt = a.grp_cnt[origin];
-        int patches = 0;
-        for (int m = lane; m < cnt; m += 64) {
-            const int mem = a.members[off + m];
-            patches += box_area(a.meta[mem], mem, HW, a.W);
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) patches += __shfl_xor(patches, d, 64);
+        const int4 info = a.row_info[row];                       // origin | leaf bit, member offset, count, patches
+        const int origin = info.x & 0x7fffffff, off = info.y, cnt = info.z;
+        const void* s0 = (info.x < 0 && a.xrows) ? a.xrows : a.S;        // 1x1 nodes were not copied out of x
         const bool divide = a.weighted_avg || cnt > 1;
-        const float den = round_to<T>(a.weighted_avg ? (float)patches : (float)cnt);
-        auto src_of = [&](int r) -> const void* {                 // 1x1 nodes were not copied out of x
-            return (a.xrows && box_area(a.meta[r], r, HW, a.W) == 1) ? a.xrows : a.S;
-        };
-        const void* s0 = src_of(origin);
+        const float den = round_to<T>(a.weighted_avg ? (float)info.w : (float)cnt);
         for (int c0 = lane * VEC; c0 < a.C; c0 += 64 * VEC) {
             Pack<T, VEC> acc = load_pack<T, VEC>(s0, (int64_t)origin * a.C + c0);
             for (int m = 1; m < cnt; ++m) {
                 const int mr = a.members[off + m];
-                const Pack<T, VEC> p = load_pack<T, VEC>(src_of(mr), (int64_t)mr * a.C + c0);
+                const void* sm = (mr < 0 && a.xrows) ? a.xrows : a.S;
+                const Pack<T, VEC> p = load_pack<T, VEC>(sm, (int64_t)(mr & 0x7fffffff) * a.C + c0);
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) acc.set(e, acc.get(e) + p.get(e));
             }
@@ -584,14 +607,6 @@ __global__ void __launch_bounds__(256) k_group_mean(TemporalArgs a) {
                 for (int e = 0; e < VEC; ++e) acc.set(e, acc.get(e) / den);
             }
             store_pack<T, VEC>(a.feat_out, (int64_t)row * a.C + c0, acc);
-        }
-        if (lane == 0) {
-            const uint32_t meta = a.meta[origin];
-            const int t = origin / HW, rem = origin - t * HW;
-            const int y1 = rem / a.W, x1 = rem - y1 * a.W;
-            a.npatch_out[row] = patches;
-            int32_t* o = a.tlbr_out + (int64_t)row * 5;
-            o[0] = t; o[1] = y1; o[2] = x1; o[3] = (int)(meta >> 16); o[4] = (int)(meta & 0xffff);
         }
     }
 }

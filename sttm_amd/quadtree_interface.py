@@ -11,6 +11,8 @@ from . import _lib
 
 _DTYPE_CODE = {torch.float32: _lib.STTM_F32, torch.bfloat16: _lib.STTM_BF16, torch.float16: _lib.STTM_F16}
 _pinned_counts = {}
+_ws_cache = {}          # device -> uint8 workspace tensor (grown on demand; safe to reuse: every call ends synchronised)
+_ws_bytes_cache = {}    # (T, H, W, C, dtype, root_level) -> bytes
 
 
 def _counts_host(device):
@@ -39,13 +41,20 @@ def quadtree_merge_raw(x, threshold, temporal_thresh, root_level, weighted_avg, 
     dev = x.device
     dtype = _DTYPE_CODE[x.dtype]
     head_dim = 0 if head_dim is None else int(head_dim)
-    nbytes = lib.sttm_quadtree_workspace_bytes(T, H, W, C, dtype, int(root_level))
-    if nbytes == 0:
-        code = lib.sttm_quadtree_num_levels(H, W, int(root_level))
-        _lib.raise_for(code if code < 0 else _lib.ERR_ARG)
+    key = (T, H, W, C, dtype, int(root_level))
+    nbytes = _ws_bytes_cache.get(key)
+    if nbytes is None:
+        nbytes = lib.sttm_quadtree_workspace_bytes(T, H, W, C, dtype, int(root_level))
+        if nbytes == 0:
+            code = lib.sttm_quadtree_num_levels(H, W, int(root_level))
+            _lib.raise_for(code if code < 0 else _lib.ERR_ARG)
+        _ws_bytes_cache[key] = nbytes
     N = T * H * W
     with torch.cuda.device(dev):
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ws = _ws_cache.get(dev)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            _ws_cache[dev] = ws
         feat = torch.empty((N, C), dtype=x.dtype, device=dev)
         npatch = torch.empty(N, dtype=torch.int32, device=dev)
         tlbr = torch.empty((N, 5), dtype=torch.int32, device=dev)
@@ -54,7 +63,7 @@ def quadtree_merge_raw(x, threshold, temporal_thresh, root_level, weighted_avg, 
         rc = lib.sttm_quadtree_merge(
             x.data_ptr(), x.stride(0), x.stride(1), x.stride(2), x.stride(3), T, C, H, W, dtype,
             float(threshold), float(temporal_thresh), int(root_level), int(bool(weighted_avg)), head_dim,
-            ws.data_ptr(), nbytes, feat.data_ptr(), npatch.data_ptr(), tlbr.data_ptr(), counts.data_ptr(),
+            ws.data_ptr(), ws.numel(), feat.data_ptr(), npatch.data_ptr(), tlbr.data_ptr(), counts.data_ptr(),
             stream.cuda_stream)
         _lib.raise_for(rc)
         host = _counts_host(dev)
