@@ -44,6 +44,7 @@ extern "C" {
 #define STTM_ERR_LAUNCH (-3)     /* HIP reported a launch error                                     */
 #define STTM_ERR_INDEX (-4)      /* root_level out of range (the reference raises IndexError)       */
 #define STTM_ERR_PARITY (-5)     /* weighted_avg on a mixed-parity level (reference: RuntimeError)  */
+#define STTM_ERR_TIMEOUT (-6)    /* sttm_wait_counts: the counts were not published in time         */
 
 /* slots of the int32 `counts` array written by sttm_quadtree_merge (device memory, >= 8 ints) */
 #define STTM_CNT_NODES 0      /* N  : nodes after the spatial stage                                  */
@@ -88,6 +89,22 @@ int sttm_quadtree_merge(const void* x, int64_t stride_t, int64_t stride_c, int64
                         void* workspace, size_t workspace_bytes,
                         void* feat_out, int32_t* npatch_out, int32_t* tlbr_out, int32_t* counts,
                         void* stream);
+
+/*
+ * Same merge, but the counts are ALSO published into `counts_host` -- int32[STTM_CNT_SLOTS] of pinned, device-mapped
+ * host memory -- by the kernel that computes N' (the one before the feature gather), with slot STTM_CNT_SLOTS-1 set
+ * to `seq` last (system-scope release).  sttm_wait_counts spins (no HIP call) until that slot equals seq: the caller
+ * learns N' -- which it needs to size the tensors it returns -- while the feature kernel is still running, and
+ * returns without a stream synchronisation; consumers of the outputs are stream-ordered as usual.
+ * counts_host may be NULL (then this is exactly sttm_quadtree_merge).
+ */
+int sttm_quadtree_merge_async(const void* x, int64_t stride_t, int64_t stride_c, int64_t stride_h, int64_t stride_w,
+                              int T, int C, int H, int W, int dtype,
+                              float threshold, float temporal_thresh, int root_level, int weighted_avg, int head_dim,
+                              void* workspace, size_t workspace_bytes,
+                              void* feat_out, int32_t* npatch_out, int32_t* tlbr_out, int32_t* counts,
+                              int32_t* counts_host, int seq, void* stream);
+int sttm_wait_counts(const int32_t* counts_host, int seq, int timeout_us);
 
 /*
  * Per-kernel timing of sttm_quadtree_merge for the benchmark's roofline leg (not part of the reference API).

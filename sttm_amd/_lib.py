@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsttm_hip.so")
 
 STTM_F32, STTM_BF16, STTM_F16 = 0, 1, 2
-ERR_ARG, ERR_UNSUPPORTED, ERR_LAUNCH, ERR_INDEX, ERR_PARITY = -1, -2, -3, -4, -5
+ERR_ARG, ERR_UNSUPPORTED, ERR_LAUNCH, ERR_INDEX, ERR_PARITY, ERR_TIMEOUT = -1, -2, -3, -4, -5, -6
 CNT_NODES, CNT_CANDIDATES, CNT_EDGES, CNT_OUT, CNT_ITERS, CNT_OVERFLOW, CNT_SLOTS = 0, 1, 2, 3, 4, 5, 8
 
 # every symbol include/sttm_hip.h declares, with its ctypes signature
@@ -22,6 +22,9 @@ SIGNATURES = {
     "sttm_quadtree_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "sttm_quadtree_merge": (_i, [_vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _f, _i, _i, _i,
                                  _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "sttm_quadtree_merge_async": (_i, [_vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _f, _i, _i, _i,
+                                       _vp, _sz, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "sttm_wait_counts": (_i, [_vp, _i, _i]),
     "sttm_profile_enable": (_i, [_i]),
     "sttm_profile_last": (_i, [ctypes.POINTER(ctypes.c_float)]),
     "sttm_merge_dst_idx": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 
 #include "sttm_kernels.h"
 
@@ -190,6 +191,33 @@ int sttm_quadtree_merge(const void* x, int64_t stride_t, int64_t stride_c, int64
                         void* workspace, size_t workspace_bytes,
                         void* feat_out, int32_t* npatch_out, int32_t* tlbr_out, int32_t* counts,
                         void* stream_) {
+    return sttm_quadtree_merge_async(x, stride_t, stride_c, stride_h, stride_w, T, C, H, W, dtype, threshold, temporal_thresh,
+                                     root_level, weighted_avg, head_dim, workspace, workspace_bytes, feat_out, npatch_out,
+                                     tlbr_out, counts, nullptr, 0, stream_);
+}
+
+int sttm_wait_counts(const int32_t* counts_host, int seq, int timeout_us) {
+    if (!counts_host) return fail(STTM_ERR_ARG, "null pointer");
+    const volatile int32_t* flag = counts_host + STTM_CNT_SLOTS - 1;
+    timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (unsigned spins = 0;; ++spins) {
+        if (*flag == seq) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return STTM_OK; }
+        __builtin_ia32_pause();
+        if ((spins & 1023u) == 1023u) {
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            const long long us = (t1.tv_sec - t0.tv_sec) * 1000000ll + (t1.tv_nsec - t0.tv_nsec) / 1000;
+            if (us > timeout_us) return STTM_ERR_TIMEOUT;
+        }
+    }
+}
+
+int sttm_quadtree_merge_async(const void* x, int64_t stride_t, int64_t stride_c, int64_t stride_h, int64_t stride_w,
+                              int T, int C, int H, int W, int dtype,
+                              float threshold, float temporal_thresh, int root_level, int weighted_avg, int head_dim,
+                              void* workspace, size_t workspace_bytes,
+                              void* feat_out, int32_t* npatch_out, int32_t* tlbr_out, int32_t* counts,
+                              int32_t* counts_host, int seq, void* stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     if (!x || !workspace || !feat_out || !npatch_out || !tlbr_out || !counts) return fail(STTM_ERR_ARG, "null pointer argument");
     if (T < 1 || C < 1) return fail(STTM_ERR_ARG, "T and C must be positive");
@@ -259,6 +287,7 @@ int sttm_quadtree_merge(const void* x, int64_t stride_t, int64_t stride_c, int64
     ta.col_mask = b.col_mask; ta.frame_cnt = b.frame_cnt; ta.colscratch = b.colscratch;
     ta.row_info = b.row_info; ta.grp_np = b.grp_np; ta.grp_cnt = b.grp_cnt; ta.grp_off = b.grp_off; ta.members = b.members;
     ta.counts = counts;
+    ta.counts_host = counts_host; ta.seq = seq;
     ta.feat_out = feat_out; ta.npatch_out = npatch_out; ta.tlbr_out = tlbr_out;
 
     hipError_t e;

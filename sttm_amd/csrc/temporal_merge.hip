@@ -510,7 +510,17 @@ __global__ void __launch_bounds__(256) k_rank(TemporalArgs a) {
             ++off;
         }
     }
-    if (t == a.T - 1 && tid == 0) a.counts[STTM_CNT_OUT] = base + tot;
+    if (t == a.T - 1 && tid == 0) {
+        const int n_out = base + tot;
+        a.counts[STTM_CNT_OUT] = n_out;
+        if (a.counts_host) {
+            // publish the counts straight into pinned host memory: the caller learns N' while k_group_mean still runs
+            for (int i = 0; i < STTM_CNT_SLOTS - 1; ++i)
+                __hip_atomic_store(a.counts_host + i, i == STTM_CNT_OUT ? n_out : a.counts[i], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(a.counts_host + STTM_CNT_SLOTS - 1, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 hipError_t launch_rank(const TemporalArgs& a, hipStream_t stream) {

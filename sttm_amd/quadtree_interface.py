@@ -15,10 +15,13 @@ _ws_cache = {}          # device -> uint8 workspace tensor (grown on demand; saf
 _ws_bytes_cache = {}    # (T, H, W, C, dtype, root_level) -> bytes
 
 
+_seq = [0]
+
+
 def _counts_host(device):
     buf = _pinned_counts.get(device)
     if buf is None:
-        buf = torch.empty(_lib.CNT_SLOTS, dtype=torch.int32).pin_memory()
+        buf = torch.zeros(_lib.CNT_SLOTS, dtype=torch.int32).pin_memory()
         _pinned_counts[device] = buf
     return buf
 
@@ -51,24 +54,31 @@ def quadtree_merge_raw(x, threshold, temporal_thresh, root_level, weighted_avg, 
         _ws_bytes_cache[key] = nbytes
     N = T * H * W
     with torch.cuda.device(dev):
-        ws = _ws_cache.get(dev)
-        if ws is None or ws.numel() < nbytes:
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            _ws_cache[dev] = ws
+        stream = torch.cuda.current_stream(dev)
+        skey = (dev, stream.cuda_stream)           # scratch is reused call after call on the SAME stream (stream-ordered)
+        cached = _ws_cache.get(skey)
+        if cached is None or cached[0].numel() < nbytes:
+            cached = (torch.empty(nbytes, dtype=torch.uint8, device=dev),
+                      torch.empty(_lib.CNT_SLOTS, dtype=torch.int32, device=dev))
+            _ws_cache[skey] = cached
+        ws, counts = cached
         feat = torch.empty((N, C), dtype=x.dtype, device=dev)
         npatch = torch.empty(N, dtype=torch.int32, device=dev)
         tlbr = torch.empty((N, 5), dtype=torch.int32, device=dev)
-        counts = torch.empty(_lib.CNT_SLOTS, dtype=torch.int32, device=dev)
-        stream = torch.cuda.current_stream(dev)
-        rc = lib.sttm_quadtree_merge(
+        host = _counts_host(dev)
+        _seq[0] = (_seq[0] % 0x3fffffff) + 1
+        seq = _seq[0]
+        rc = lib.sttm_quadtree_merge_async(
             x.data_ptr(), x.stride(0), x.stride(1), x.stride(2), x.stride(3), T, C, H, W, dtype,
             float(threshold), float(temporal_thresh), int(root_level), int(bool(weighted_avg)), head_dim,
             ws.data_ptr(), ws.numel(), feat.data_ptr(), npatch.data_ptr(), tlbr.data_ptr(), counts.data_ptr(),
-            stream.cuda_stream)
+            host.data_ptr(), seq, stream.cuda_stream)
         _lib.raise_for(rc)
-        host = _counts_host(dev)
-        host.copy_(counts, non_blocking=True)
-        stream.synchronize()                       # the one unavoidable sync: output sizes are data dependent
+        # Output sizes are data dependent, so the host must learn N' -- but only N': the rank kernel publishes the
+        # counts into pinned memory and we spin on that, returning while the feature gather is still running.
+        if lib.sttm_wait_counts(host.data_ptr(), seq, 2_000_000) != 0:
+            host.copy_(counts, non_blocking=True)  # fallback: classic D2H + stream sync
+            stream.synchronize()
     cnt = host.tolist()
     if cnt[_lib.CNT_OVERFLOW]:
         raise RuntimeError("libsttm_hip: internal list overflow (please report): counts=%s" % cnt)
