@@ -265,6 +265,12 @@ int sttm_quadtree_merge_async(const void* x, int64_t stride_t, int64_t stride_c,
     // dense [T*H*W, C] input: the rows of 1x1 nodes are read from x by the later kernels instead of being copied to S
     const bool dense = stride_w == C && stride_h == (int64_t)W * C && stride_t == (int64_t)H * W * C;
     sa.leaves_in_x = dense ? 1 : 0;
+    {
+        const char* np = getenv("STTM_PIPELINE");
+        sa.pipeline = (np && np[0] == '1') ? 1 : 0;
+        const char* dm = getenv("STTM_K1_ABLATE");      // only honoured by the profile leg: results are invalid
+        sa.dbg_mode = (dm && g_prof_on) ? atoi(dm) : 0;
+    }
     sa.S = b.S; sa.meta = b.meta; sa.inrm = b.inrm; sa.rc_list = b.rc_list;
     sa.rc_stride = p.rc_stride;
     sa.counts = counts;
@@ -296,6 +302,11 @@ int sttm_quadtree_merge_async(const void* x, int64_t stride_t, int64_t stride_c,
     if ((e = sttm::launch_spatial(sa, dtype, vec, nt, stream)) != hipSuccess)
         return fail(STTM_ERR_LAUNCH, "spatial kernel: %s", hipGetErrorString(e));
     prof_mark(1, stream);
+    if (sa.dbg_mode) {          // ablation run: only the spatial kernel was launched, its outputs are not valid
+        for (int i = 2; i <= kProfSlots; ++i) prof_mark(i, stream);
+        g_prof_valid = true; g_prof_ran[0] = true; g_prof_ran[1] = g_prof_ran[2] = g_prof_ran[3] = false;
+        return STTM_OK;
+    }
     const bool pairs = temporal_thresh > 0.f && T > 1;
     if (pairs) {
         if ((e = sttm::launch_pairs(ta, stream)) != hipSuccess)

@@ -302,6 +302,122 @@ __device__ __forceinline__ bool cosine_at_least(float dot, float n2a, float n2b,
     return d * fabs(d) >= lo_sq_signed * (a * b);
 }
 
+// Same as locate() for a node whose depth DEPTH is known at compile time: every loop unrolls, the per-level
+// arrays are register-allocated (the generic version indexes them dynamically and lands in scratch memory).
+template <int DEPTH>
+__device__ __forceinline__ NodeLoc locate_static(const LevelDims& g, int I, int J, int rel) {
+    NodeLoc L;
+    L.depth = DEPTH;
+    L.i = I; L.j = J; L.valid = true;
+    L.path[0] = 0; L.pi[0] = I; L.pj[0] = J; L.slot[0] = 0;
+    int id = 0;
+#pragma unroll
+    for (int s = 1; s <= DEPTH; ++s) {
+        const int k = (rel >> (2 * (DEPTH - s))) & 3;
+        const CellGeo c = cell_children(g, s - 1, L.i, L.j);
+        if ((k >> 1) >= c.rc || (k & 1) >= c.cc) L.valid = false;
+        L.i = c.rs + (k >> 1);
+        L.j = c.cs + (k & 1);
+        id = 4 * id + 1 + k;
+        L.path[s] = id;
+        L.slot[s] = k;
+        if (!L.valid) { L.i = 0; L.j = 0; }
+        L.pi[s] = L.i; L.pj[s] = L.j;
+    }
+    return L;
+}
+
+// one (parent, slot) cosine test for parents of a compile-time depth
+template <int D, int DEPTH>
+__device__ __forceinline__ void parent_slot_test(const SpatialArgs& a, int I, int J, int rel, int k, const float* stat, int* stop) {
+    using TC = TreeConst<D>;
+    const NodeLoc L = locate_static<DEPTH>(a.dims, I, J, rel);
+    if (!L.valid) return;
+    const int p = depth_base(DEPTH) + rel;
+    const CellGeo c = cell_children(a.dims, DEPTH, L.i, L.j);
+    const bool vk = (k >> 1) < c.rc && (k & 1) < c.cc;
+    const float n2c = vk ? stat[4 * p + 1 + k] : stat[TC::alias_id(DEPTH + 1)];
+    if (!cosine_at_least(stat[TC::dot_id(p, k)], stat[p], n2c, a.thr_lo_sq)) stop[p] = 0;
+}
+
+// Phases 2-4 of one (frame, root cell) item, entered after the per-wave partial statistics are in LDS and a
+// barrier: fixed-order cross-wave sums, every (parent, slot) cosine test + every node's inverse norm in parallel,
+// then one thread per leaf position emits.  Ends with a barrier; orow[] then maps tree node -> row in S (or -1).
+template <int D>
+__device__ __forceinline__ void decide_and_emit(const SpatialArgs& a, int t, int I, int J, int item, const float* part,
+                                                float* stat, int* stop, int* orow, int* lcount, double* inrm_l, int nwave) {
+    using TC = TreeConst<D>;
+    constexpr int NSTAT = TC::NSTAT;
+    const LevelDims& g = a.dims;
+    const int tid = threadIdx.x;
+    const int HW = a.H * a.W;
+    int* rc_list = a.rc_list + (int64_t)item * a.rc_stride;
+    // ---- phase 2: cross-wave sum in a fixed order ------------------------------------------------------------
+    for (int s2 = tid; s2 < NSTAT; s2 += blockDim.x) {
+        float acc = 0.f;
+        for (int w = 0; w < nwave; ++w) acc += part[w * NSTAT + s2];
+        stat[s2] = acc;
+    }
+    __syncthreads();
+    // ---- phase 3: every (parent, slot) cosine test and every node's inverse norm, one thread each, spread over
+    //      the waves so the four SIMDs work side by side -----------------------------------------------------------
+    for (int base = 0; base < 4 * TC::NPAR + TC::NNODE; base += blockDim.x) {
+        const int e = base + (tid & 63) * nwave + (tid >> 6);  // lane-major: consecutive items land on different waves
+        if (e < 4 * TC::NPAR) {
+            const int p = e >> 2, k = e & 3;
+            if constexpr (D >= 2) { if (p < depth_base(1)) parent_slot_test<D, 0>(a, I, J, p, k, stat, stop); }
+            if constexpr (D >= 3) { if (p >= depth_base(1) && p < depth_base(2)) parent_slot_test<D, 1>(a, I, J, p - depth_base(1), k, stat, stop); }
+            if constexpr (D >= 4) { if (p >= depth_base(2) && p < depth_base(3)) parent_slot_test<D, 2>(a, I, J, p - depth_base(2), k, stat, stop); }
+            if constexpr (D >= 5) { if (p >= depth_base(3) && p < depth_base(4)) parent_slot_test<D, 3>(a, I, J, p - depth_base(3), k, stat, stop); }
+        } else if (e < 4 * TC::NPAR + TC::NNODE) {
+            const int n = e - 4 * TC::NPAR;
+            inrm_l[n] = 1.0 / (sqrt((double)stat[n]) + 1e-8);     // temporal stage: x / (|x| + 1e-8)
+        }
+    }
+    __syncthreads();
+    // ---- phase 4: emission, one thread per leaf position of the root cell -------------------------------------
+    // The leaf-level node learns its first stopped ancestor (or itself): that node is emitted; the leaf that is its
+    // top-left descendant (all slots below it are 0) is the node's origin and writes the node's metadata.
+    for (int q = tid; q < TC::NLEAF; q += blockDim.x) {
+        const NodeLoc L = locate_static<D - 1>(g, I, J, q);
+        if (!L.valid) continue;
+        int da = D - 1;
+#pragma unroll
+        for (int d = D - 2; d >= 0; --d) {
+            if (stop[L.path[d]]) da = d;                       // ends at the SHALLOWEST stopped ancestor
+        }
+        bool origin = true;
+        int emit_node = L.path[D - 1], hi_i = L.i, hi_j = L.j;
+#pragma unroll
+        for (int d = D - 1; d >= 0; --d) {
+            if (d > da) origin = origin && (L.slot[d] == 0);
+            if (d == da) { emit_node = L.path[d]; hi_i = L.pi[d]; hi_j = L.pj[d]; }
+        }
+        const int leaf_row = t * HW + L.i * a.W + L.j;
+        if (!origin) { a.meta[leaf_row] = 0u; continue; }
+        // box of the emitted ancestor: top-left is this leaf; bottom-right follows last children down
+#pragma unroll
+        for (int m = 0; m < D - 1; ++m) {
+            if (m >= da) {
+                hi_i = child_start(hi_i, g.h[m + 1]) + child_count(hi_i, g.h[m + 1]) - 1;
+                hi_j = child_start(hi_j, g.w[m + 1]) + child_count(hi_j, g.w[m + 1]) - 1;
+            }
+        }
+        const int y2 = hi_i + 1, x2 = hi_j + 1;
+        a.meta[leaf_row] = ((uint32_t)y2 << 16) | (uint32_t)x2;
+        a.inrm[leaf_row] = inrm_l[emit_node];
+        orow[emit_node] = leaf_row;
+        const int pos = atomicAdd(lcount, 1);
+        rc_list[1 + pos] = (L.i << 24) | (L.j << 16) | (y2 << 8) | x2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        rc_list[0] = *lcount;
+        if (I == 0 && J == 0) a.frame_cnt[t] = 0;            // consumed (atomically) by the label kernels
+    }
+    if (item == 0 && tid < STTM_CNT_SLOTS) a.counts[tid] = 0;
+}
+
 template <typename T, int VEC, int BL, int UL, int MAXNT>
 __global__ void __launch_bounds__(MAXNT, 4) k_spatial(SpatialArgs a) {
     constexpr int D = BL + UL;
@@ -370,6 +486,10 @@ __global__ void __launch_bounds__(MAXNT, 4) k_spatial(SpatialArgs a) {
     if constexpr (UL == 0) {
         block_geometry<BL>(g, 0, I, J, true, bg);
         load_and_pool_block<T, VEC, BL>(cx, t, I, J, true, bg, regs);
+        if (a.dbg_mode == 2) {                  // ablation: loads + pooling only (one store keeps them alive)
+            if (cx.active) store_pack<T, VEC>(a.S, (int64_t)blockIdx.x * a.C + cx.c0, regs.top);
+            return;
+        }
         block_stats<T, VEC, BL, D>(regs, bg, true, 0, 0, alias, mypart, lane);
         root = regs.top;
     } else if constexpr (UL == 1) {
@@ -444,68 +564,8 @@ __global__ void __launch_bounds__(MAXNT, 4) k_spatial(SpatialArgs a) {
     }
     __syncthreads();
 
-    const int HW = a.H * a.W;
-    int* rc_list = a.rc_list + (int64_t)blockIdx.x * a.rc_stride;
-    // fixed-order cross-wave sum of one statistic: identical bits in whichever thread evaluates it
-    auto stat_of = [&](int id) { float acc = 0.f; for (int w = 0; w < nwave; ++w) acc += part[w * NSTAT + id]; return acc; };
-    // emission of one leaf position (shared by both paths): `da` = depth of the first stopped ancestor (or D-1)
-    auto emit_leaf = [&](const NodeLoc& L, int da) {
-        bool origin = true;
-        for (int d = da + 1; d <= D - 1; ++d) origin = origin && (L.slot[d] == 0);
-        const int leaf_row = t * HW + L.i * a.W + L.j;
-        if (!origin) { a.meta[leaf_row] = 0u; return; }
-        // box of the emitted ancestor: top-left is this leaf; bottom-right follows last children down
-        int hi_i = L.pi[da], hi_j = L.pj[da];
-        for (int m = da; m < D - 1; ++m) {
-            hi_i = child_start(hi_i, g.h[m + 1]) + child_count(hi_i, g.h[m + 1]) - 1;
-            hi_j = child_start(hi_j, g.w[m + 1]) + child_count(hi_j, g.w[m + 1]) - 1;
-        }
-        const int y2 = hi_i + 1, x2 = hi_j + 1;
-        a.meta[leaf_row] = ((uint32_t)y2 << 16) | (uint32_t)x2;
-        a.inrm[leaf_row] = inrm_l[L.path[da]];
-        orow[L.path[da]] = leaf_row;
-        const int pos = atomicAdd(lcount, 1);
-        rc_list[1 + pos] = (L.i << 24) | (L.j << 16) | (y2 << 8) | x2;
-    };
-
-    // ---- phase 2: cross-wave sum in a fixed order ------------------------------------------------------------
-    for (int s2 = tid; s2 < NSTAT; s2 += blockDim.x) stat[s2] = stat_of(s2);
-    __syncthreads();
-    // ---- phase 3: every (parent, slot) cosine test and every node's inverse norm, one thread each, spread over
-    //      the waves so the four SIMDs work side by side -----------------------------------------------------------
-    for (int base = 0; base < 4 * TC::NPAR + TC::NNODE; base += blockDim.x) {
-        const int e = base + (tid & 63) * nwave + (tid >> 6);  // lane-major: consecutive items land on different waves
-        if (e < 4 * TC::NPAR) {
-            const int p = e >> 2, k = e & 3;
-            const NodeLoc L = locate(g, I, J, p);
-            if (L.valid) {
-                const CellGeo c = cell_children(g, L.depth, L.i, L.j);
-                const bool vk = (k >> 1) < c.rc && (k & 1) < c.cc;
-                const float n2c = vk ? stat[4 * p + 1 + k] : stat[TC::alias_id(L.depth + 1)];
-                if (!cosine_at_least(stat[TC::dot_id(p, k)], stat[p], n2c, a.thr_lo_sq)) stop[p] = 0;
-            }
-        } else if (e < 4 * TC::NPAR + TC::NNODE) {
-            const int n = e - 4 * TC::NPAR;
-            inrm_l[n] = 1.0 / (sqrt((double)stat[n]) + 1e-8);     // temporal stage: x / (|x| + 1e-8)
-        }
-    }
-    __syncthreads();
-    // ---- phase 4: emission, one thread per leaf position of the root cell -------------------------------------
-    for (int q = tid; q < TC::NLEAF; q += blockDim.x) {
-        const NodeLoc L = locate(g, I, J, depth_base(D - 1) + q);
-        if (!L.valid) continue;
-        int da = D - 1;
-        for (int d = 0; d < D - 1; ++d) {
-            if (stop[L.path[d]]) { da = d; break; }
-        }
-        emit_leaf(L, da);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        rc_list[0] = *lcount;
-        if (rcell == 0) a.frame_cnt[t] = 0;                  // consumed (atomically) by the label kernels
-    }
-    if (blockIdx.x == 0 && tid < STTM_CNT_SLOTS) a.counts[tid] = 0;
+    if (a.dbg_mode == 1) return;
+    decide_and_emit<D>(a, t, I, J, blockIdx.x, part, stat, stop, orow, lcount, inrm_l, nwave);
 
     // ---- phase 5: store the emitted features ----------------------------------------------------------------
     if constexpr (UL == 0) {
@@ -558,6 +618,124 @@ __global__ void __launch_bounds__(MAXNT, 4) k_spatial(SpatialArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Pipelined variant for 3-level trees (the production configurations: 14x14 / 27x27 / 13x24 at root_level 1).
+// Persistent workgroups walk the (frame, root cell) items with a stride of gridDim.x and keep TWO items in
+// registers: while item i is pooled, reduced, decided and stored, the 16 leaf rows of item i+stride are already
+// in flight.  The plain kernel alternates "everyone loads" / "everyone computes" chip-wide (2048 workgroups in two
+// residency rounds); here every CU has loads outstanding all the time.  All HBM loads of an item (leaves + the
+// alias leaves of row-0 / col-0 items) are issued together, so no later load forces a wait on the prefetch.
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int VEC> struct Item3 {
+    Pack<T, VEC> leaf[4][4];
+    Pack<T, VEC> araw[4];      // leaves under level-1 cell (0,0): the alias sources
+};
+struct Item3Geo {
+    int t, I, J;
+    BlockGeo bg;
+    bool need1, need2;         // this item has parents with invalid slots at level 0 / level 1
+    bool av[4];                // validity of the 4 children of level-1 cell (0,0)
+};
+
+__device__ __forceinline__ void item3_geometry(const LevelDims& g, int item, Item3Geo& q) {
+    const int R = g.h[0] * g.w[0];
+    q.t = item / R;
+    const int rc = item - q.t * R;
+    q.I = rc / g.w[0]; q.J = rc - q.I * g.w[0];
+    block_geometry<3>(g, 0, q.I, q.J, true, q.bg);
+    q.need1 = ((g.h[1] & 1) && q.I == 0) || ((g.w[1] & 1) && q.J == 0);
+    q.need2 = ((g.h[2] & 1) && q.I == 0) || ((g.w[2] & 1) && q.J == 0);
+    const CellGeo c = cell_children(g, 1, 0, 0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q.av[k] = (k >> 1) < c.rc && (k & 1) < c.cc;
+}
+
+template <typename T, int VEC>
+__device__ __forceinline__ void item3_load(const SpatialCtx& cx, const Item3Geo& q, Item3<T, VEC>& r) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r.leaf[k][e] = load_leaf<T, VEC>(cx, q.t, q.bg.li[k][e], q.bg.lj[k][e], q.bg.v2[k][e]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        r.araw[k] = load_leaf<T, VEC>(cx, q.t, k >> 1, k & 1, (q.need1 && q.av[k]) || (q.need2 && k == 0));
+}
+
+template <typename T, int VEC, int MAXNT>
+__global__ void __launch_bounds__(MAXNT, 2) k_spatial3_pipe(SpatialArgs a) {
+    constexpr int D = 3;
+    using TC = TreeConst<D>;
+    constexpr int NSTAT = TC::NSTAT;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int nwave = blockDim.x / kWave;
+    double* inrm_l = reinterpret_cast<double*>(smem_raw);
+    float* part = reinterpret_cast<float*>(inrm_l + TC::NNODE);
+    float* stat = part + nwave * NSTAT;
+    int* stop = reinterpret_cast<int*>(stat + NSTAT);
+    int* orow = stop + TC::NPAR;
+    int* lcount = orow + TC::NNODE;
+
+    const LevelDims& g = a.dims;
+    const int total = a.T * g.h[0] * g.w[0];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    SpatialCtx cx;
+    cx.x = a.x; cx.sT = a.sT; cx.sH = a.sH; cx.sW = a.sW;
+    cx.c0 = (int64_t)tid * VEC;
+    cx.active = cx.c0 < a.C;
+    cx.sum_mode = a.sum_mode != 0;
+    float* mypart = part + wave * NSTAT;
+
+    auto process = [&](const Item3Geo& q, Item3<T, VEC>& it, int item) {
+        __syncthreads();                               // the previous item's readers of LDS are done
+        for (int s = tid; s < nwave * NSTAT; s += blockDim.x) part[s] = 0.f;
+        for (int s = tid; s < TC::NNODE; s += blockDim.x) orow[s] = -1;
+        for (int s = tid; s < TC::NPAR; s += blockDim.x) stop[s] = 1;
+        if (tid == 0) *lcount = 0;
+        // pyramid
+        BlockRegs<T, VEC> r;
+        Pack<T, VEC> alias[D];
+        alias[0].zero();
+        alias[2] = it.araw[0];
+        if (q.need1) alias[1] = pool4<T, VEC>(it.araw, q.av, cx.sum_mode); else alias[1].zero();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r.leaf[k][e] = it.leaf[k][e];
+            if (q.bg.v1[k]) r.mid[k] = pool4<T, VEC>(r.leaf[k], q.bg.v2[k], cx.sum_mode); else r.mid[k].zero();
+        }
+        r.top = pool4<T, VEC>(r.mid, q.bg.v1, cx.sum_mode);
+        __syncthreads();                               // LDS cleared
+        if (q.need1) { const float tot = wave_sum(dot_pack(alias[1], alias[1])); if (lane == 0) mypart[TC::alias_id(1)] = tot; }
+        if (q.need2) { const float tot = wave_sum(dot_pack(alias[2], alias[2])); if (lane == 0) mypart[TC::alias_id(2)] = tot; }
+        block_stats<T, VEC, 3, D>(r, q.bg, true, 0, 0, alias, mypart, lane);
+        __syncthreads();
+        decide_and_emit<D>(a, q.t, q.I, q.J, item, part, stat, stop, orow, lcount, inrm_l, nwave);
+        block_store<T, VEC, 3>(r, 0, orow, a.S, a.C, cx, a.leaves_in_x != 0);
+    };
+
+    Item3<T, VEC> A, B;
+    Item3Geo qa, qb;
+    int item = blockIdx.x;
+    if (item >= total) return;
+    item3_geometry(g, item, qa);
+    item3_load<T, VEC>(cx, qa, A);
+    while (true) {
+        int next = item + gridDim.x;
+        bool more = next < total;
+        if (more) { item3_geometry(g, next, qb); item3_load<T, VEC>(cx, qb, B); }
+        process(qa, A, item);
+        if (!more) break;
+        item = next;
+        next = item + gridDim.x;
+        more = next < total;
+        if (more) { item3_geometry(g, next, qa); item3_load<T, VEC>(cx, qa, A); }
+        process(qb, B, item);
+        if (!more) break;
+        item = next;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------------------------------
@@ -575,7 +753,23 @@ static hipError_t launch_bl_ul(const SpatialArgs& a, int grid, int nt, hipStream
 }
 
 template <typename T, int VEC>
+static hipError_t launch_pipe3(const SpatialArgs& a, int items, int nt, hipStream_t stream) {
+    using TC = TreeConst<3>;
+    const int nwave = nt / kWave;
+    const size_t smem = sizeof(double) * TC::NNODE + sizeof(float) * ((size_t)nwave * TC::NSTAT + TC::NSTAT) +
+                        sizeof(int) * (TC::NPAR + TC::NNODE + 4);
+    // two resident workgroups per CU at <= 512 threads (256 VGPRs each); one above
+    int grid = nt <= 512 ? 512 : 256;
+    if (grid > items) grid = items;
+    if (nt <= 256) hipLaunchKernelGGL((k_spatial3_pipe<T, VEC, 256>), dim3(grid), dim3(nt), smem, stream, a);
+    else if (nt <= 512) hipLaunchKernelGGL((k_spatial3_pipe<T, VEC, 512>), dim3(grid), dim3(nt), smem, stream, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+template <typename T, int VEC>
 static hipError_t launch_depth(const SpatialArgs& a, int grid, int nt, hipStream_t stream) {
+    if (a.dims.n_level == 3 && nt <= 512 && grid >= 1024 && a.pipeline) return launch_pipe3<T, VEC>(a, grid, nt, stream);
     switch (a.dims.n_level) {
         case 1: return launch_bl_ul<T, VEC, 1, 0>(a, grid, nt, stream);
         case 2: return launch_bl_ul<T, VEC, 2, 0>(a, grid, nt, stream);

@@ -13,6 +13,8 @@ struct SpatialArgs {
     float threshold;
     double thr_lo_sq;         // lo*|lo| with lo = smallest real that rounds (fp32, RNE) to >= threshold
     int sum_mode;             // weighted_avg: sum-pool pyramid
+    int pipeline;             // opt-in: persistent double-buffered 3-level kernel (measured slower on MI355X)
+    int dbg_mode;             // ablation (sttm_debug_spatial_ms only): 1 = stop after the statistics, 2 = loads + pooling only
     int leaves_in_x;          // x is a dense [T*H*W, C] matrix: 1x1 nodes are NOT copied to S (consumers read x)
     // outputs
     void* S;                  // [T*H*W, C] node features at their origin rows (input dtype)
