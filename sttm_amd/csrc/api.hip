@@ -97,7 +97,7 @@ void root_extent_host(const sttm::LevelDims& g, int I, int J, int* ah, int* aw) 
 
 struct Buffers {
     char* S; uint32_t* meta; double* inrm; int* rc_list;
-    int32_t *edges, *edge_cnt, *cand_cnt; unsigned long long* col_mask; int32_t *frame_cnt, *colscratch;
+    int32_t *edges, *edge_cnt, *cand_cnt; unsigned long long* col_mask; int32_t *frame_cnt, *bar, *colscratch;
     int4* row_info; int32_t *grp_np, *grp_cnt, *grp_off, *members;
 };
 
@@ -116,6 +116,7 @@ size_t carve_all(const Plan& p, int T, int C, int dtype, char* base, Buffers* b)
     o.cand_cnt = c.take<int32_t>(nfr * 4);
     o.col_mask = c.take<unsigned long long>((size_t)p.R * 8);
     o.frame_cnt = c.take<int32_t>((size_t)T * 4);
+    o.bar = c.take<int32_t>(16);
     o.colscratch = c.take<int32_t>(N * 16);
     o.row_info = c.take<int4>(N * 16);
     o.grp_np = c.take<int32_t>(N * 4);
@@ -275,6 +276,7 @@ int sttm_quadtree_merge_async(const void* x, int64_t stride_t, int64_t stride_c,
     sa.rc_stride = p.rc_stride;
     sa.counts = counts;
     sa.frame_cnt = b.frame_cnt;
+    sa.bar = b.bar;
 
     sttm::TemporalArgs ta;
     memset(&ta, 0, sizeof(ta));
@@ -290,7 +292,11 @@ int sttm_quadtree_merge_async(const void* x, int64_t stride_t, int64_t stride_c,
     }
     ta.S = b.S; ta.xrows = dense ? x : nullptr; ta.meta = b.meta; ta.inrm = b.inrm; ta.rc_list = b.rc_list; ta.rc_stride = p.rc_stride;
     ta.edges = b.edges; ta.ecap = p.ecap; ta.edge_cnt = b.edge_cnt; ta.cand_cnt = b.cand_cnt;
-    ta.col_mask = b.col_mask; ta.frame_cnt = b.frame_cnt; ta.colscratch = b.colscratch;
+    ta.col_mask = b.col_mask; ta.frame_cnt = b.frame_cnt; ta.bar = b.bar;
+    {
+        const char* nf = getenv("STTM_NO_FUSE_LABELS");
+        ta.no_fuse = (nf && nf[0] == '1') ? 1 : 0;
+    } ta.colscratch = b.colscratch;
     ta.row_info = b.row_info; ta.grp_np = b.grp_np; ta.grp_cnt = b.grp_cnt; ta.grp_off = b.grp_off; ta.members = b.members;
     ta.counts = counts;
     ta.counts_host = counts_host; ta.seq = seq;
@@ -313,9 +319,12 @@ int sttm_quadtree_merge_async(const void* x, int64_t stride_t, int64_t stride_c,
             return fail(STTM_ERR_LAUNCH, "pairs kernel: %s", hipGetErrorString(e));
     }
     prof_mark(2, stream);
-    if ((e = sttm::launch_col_labels(ta, true, stream)) != hipSuccess ||
-        (e = sttm::launch_col_labels(ta, false, stream)) != hipSuccess ||
-        (e = sttm::launch_rank(ta, stream)) != hipSuccess)
+    if (sttm::labels_can_fuse(ta)) {
+        if ((e = sttm::launch_labels_fused(ta, stream)) != hipSuccess)
+            return fail(STTM_ERR_LAUNCH, "fused label kernel: %s", hipGetErrorString(e));
+    } else if ((e = sttm::launch_col_labels(ta, true, stream)) != hipSuccess ||
+               (e = sttm::launch_col_labels(ta, false, stream)) != hipSuccess ||
+               (e = sttm::launch_rank(ta, stream)) != hipSuccess)
         return fail(STTM_ERR_LAUNCH, "label kernels: %s", hipGetErrorString(e));
     prof_mark(3, stream);
     if ((e = sttm::launch_group_mean(ta, stream)) != hipSuccess)

@@ -416,6 +416,7 @@ __device__ __forceinline__ void decide_and_emit(const SpatialArgs& a, int t, int
         if (I == 0 && J == 0) a.frame_cnt[t] = 0;            // consumed (atomically) by the label kernels
     }
     if (item == 0 && tid < STTM_CNT_SLOTS) a.counts[tid] = 0;
+    if (item == 0 && tid < 2) a.bar[tid] = 0;
 }
 
 template <typename T, int VEC, int BL, int UL, int MAXNT>

@@ -24,6 +24,7 @@ struct SpatialArgs {
     int rc_stride;
     int32_t* counts;          // STTM_CNT_* slots (zeroed here, filled by the later kernels)
     int32_t* frame_cnt;       // [T] zeroed here for the label kernels
+    int32_t* bar;             // [2] zeroed here (grid-barrier counters of the fused label kernel)
 };
 hipError_t launch_spatial(const SpatialArgs& a, int dtype, int vec, int nt, hipStream_t stream);
 
@@ -48,6 +49,8 @@ struct TemporalArgs {
     int32_t* cand_cnt;        // [(T-1)*R]
     unsigned long long* col_mask;   // [R] per-column idempotency history (bit k = idempotent after iteration k+1)
     int32_t* frame_cnt;       // [T] survivors per frame (zeroed by the spatial kernel)
+    int32_t* bar;             // [2] grid-barrier counters of the fused label kernel (zeroed by the spatial kernel)
+    int no_fuse;              // debug/test: use the three-kernel label path
     int32_t* colscratch;      // [4*T*H*W] label arrays of columns that do not fit LDS
     int4* row_info;           // [T*H*W] per output row: origin | leaf bit, member offset, member count, patches
     int32_t* grp_np;          // [T*H*W] by origin row: patches covered by the group
@@ -65,6 +68,8 @@ struct TemporalArgs {
 hipError_t launch_pairs(const TemporalArgs& a, hipStream_t stream);
 hipError_t launch_col_labels(const TemporalArgs& a, bool probe, hipStream_t stream);
 hipError_t launch_rank(const TemporalArgs& a, hipStream_t stream);
+bool labels_can_fuse(const TemporalArgs& a);
+hipError_t launch_labels_fused(const TemporalArgs& a, hipStream_t stream);
 hipError_t launch_group_mean(const TemporalArgs& a, hipStream_t stream);
 bool col_labels_use_gmem(const TemporalArgs& a);
 

@@ -257,7 +257,64 @@ __device__ __forceinline__ void column_iteration(int* rep, int* rep2, const int*
     __syncthreads();
 }
 
-template <bool FINAL, bool GMEM>
+// Grid-wide barrier among the (co-resident) column workgroups of the fused kernel: agent-scope release before
+// arriving, relaxed polling, agent-scope acquire after (cdna guide G16).  The spin is bounded: on a timeout the
+// overflow counter is raised (the Python wrapper then fails loudly) instead of hanging the GPU.
+__device__ __forceinline__ void grid_barrier(int32_t* counter, int target, int32_t* overflow) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long t0 = wall_clock64();                       // 100 MHz
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (wall_clock64() - t0 > 20000000ll) { atomicAdd(overflow, 1); break; }    // 0.2 s
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+
+// rank of the survivors of frame t by one wave: rows of earlier frames (prefix) + ballot scan over the H*W origins
+__device__ __forceinline__ void rank_frame_wave(const TemporalArgs& a, int t, int prefix, int lane) {
+    const int HW = a.H * a.W, N = a.T * HW;
+    int off = prefix;
+    for (int base = 0; base < HW; base += 64) {
+        const int p = base + lane;
+        const int origin = t * HW + p;
+        const int cnt = p < HW ? a.grp_cnt[origin] : 0;
+        const unsigned long long m = __ballot(cnt > 0);
+        const int mine = off + __popcll(m & ((1ull << lane) - 1ull));
+        if (cnt > 0 && mine < N) {
+            const uint32_t meta = a.meta[origin];
+            const int np = a.grp_np[origin];
+            const int y1 = p / a.W, x1 = p - y1 * a.W;
+            const int y2 = (int)(meta >> 16), x2 = (int)(meta & 0xffff);
+            const bool leaf = (y2 - y1) == 1 && (x2 - x1) == 1;
+            a.row_info[mine] = make_int4(origin | (leaf ? kLeafBit : 0), a.grp_off[origin], cnt, np);
+            a.npatch_out[mine] = np;
+            int32_t* o = a.tlbr_out + (int64_t)mine * 5;
+            o[0] = t; o[1] = y1; o[2] = x1; o[3] = y2; o[4] = x2;
+        }
+        off += __popcll(m);
+    }
+}
+
+__device__ __forceinline__ void publish_counts(const TemporalArgs& a, int n_out) {
+    a.counts[STTM_CNT_OUT] = n_out;
+    if (a.counts_host) {
+        // straight into pinned host memory: the caller learns N' while k_group_mean still runs
+        for (int i = 0; i < STTM_CNT_SLOTS - 1; ++i)
+            __hip_atomic_store(a.counts_host + i, i == STTM_CNT_OUT ? n_out : a.counts[i], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(a.counts_host + STTM_CNT_SLOTS - 1, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+enum { COL_PROBE = 0, COL_FINAL = 1, COL_FUSED = 2 };
+
+template <int MODE, bool GMEM>
 __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     __shared__ int flags[2];
@@ -299,7 +356,8 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
     for (int i = tid; i < slots; i += nt) { cst<GMEM>(rep + i, i); cst<GMEM>(rep2 + i, i); }
     __syncthreads();
 
-    if constexpr (!FINAL) {
+    int probe_iters = 0;
+    if (MODE != COL_FINAL && temporal) {
         // ---- PROBE: iterate to the fixed point, remember after which iterations the labels were idempotent --
         unsigned long long mask = 0ull;
         int it = 0;
@@ -315,16 +373,19 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
         }
         if (tid == 0) {
             mask |= ~0ull << (it - 1);           // the labels no longer move: every later iteration is idempotent
-            a.col_mask[r] = mask;
+            __hip_atomic_store(a.col_mask + r, mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (overflow) atomicAdd(a.counts + STTM_CNT_OVERFLOW, 1);
         }
-        return;
-    } else {
-        // ---- FINAL: K = first iteration after which EVERY column is idempotent; replay exactly K iterations --
+        probe_iters = it;
+    }
+    if constexpr (MODE == COL_PROBE) return;
+    if constexpr (MODE == COL_FUSED) grid_barrier(a.bar + 0, R, a.counts + STTM_CNT_OVERFLOW);
+    {
+        // ---- FINAL: K = first iteration after which EVERY column is idempotent; labels after exactly K iterations --
         int K = 0;
         if (temporal) {
             unsigned long long m = ~0ull;
-            for (int c = tid; c < R; c += nt) m &= a.col_mask[c];
+            for (int c = tid; c < R; c += nt) m &= __hip_atomic_load(a.col_mask + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) m &= __shfl_xor(m, d, 64);
             if (lane == 0) wmask[wave] = m;
@@ -332,7 +393,15 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
             unsigned long long all = ~0ull;
             for (int w = 0; w < nwave; ++w) all &= wmask[w];
             K = all ? __ffsll((long long)all) : kMaxProbeIters;      // lowest set bit index + 1
-            for (int it = 0; it < K; ++it) column_iteration<GMEM>(rep, rep2, edges, E, slots, flags);
+            // fused: this column already sits at its fixed point, reached after probe_iters - 1 iterations; that is the
+            // answer whenever K is at least that.  Otherwise (and in the two-kernel path) replay exactly K iterations.
+            if (MODE == COL_FINAL || K < probe_iters - 1) {
+                if (MODE == COL_FUSED) {
+                    for (int i = tid; i < slots; i += nt) { cst<GMEM>(rep + i, i); cst<GMEM>(rep2 + i, i); }
+                    __syncthreads();
+                }
+                for (int it = 0; it < K; ++it) column_iteration<GMEM>(rep, rep2, edges, E, slots, flags);
+            }
         }
         // from here: rep = final labels; rep2, the edge array and `mem` are free
         int* gcnt = rep2;
@@ -452,6 +521,23 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
             if (r == 0) a.counts[STTM_CNT_ITERS] = K;
         }
     }
+    if constexpr (MODE == COL_FUSED) {
+        // ---- RANK: every column has published its groups and per-frame survivor counts ------------------------
+        grid_barrier(a.bar + 1, R, a.counts + STTM_CNT_OVERFLOW);
+        int* fpre = reinterpret_cast<int*>(smem_raw);          // [T] exclusive prefix of frame_cnt (LDS is free now)
+        int total = 0;
+        {
+            const int per = (a.T + nt - 1) / nt;
+            const int lo = tid * per < a.T ? tid * per : a.T, hi = lo + per < a.T ? lo + per : a.T;
+            int mine = 0;
+            for (int t = lo; t < hi; ++t) mine += a.frame_cnt[t];
+            int off = block_exclusive_scan(mine, wsum, &total);
+            for (int t = lo; t < hi; ++t) { fpre[t] = off; off += a.frame_cnt[t]; }
+        }
+        __syncthreads();
+        for (int t = r * nwave + wave; t < a.T; t += R * nwave) rank_frame_wave(a, t, fpre[t], lane);
+        if (r == 0 && tid == 0) publish_counts(a, total);
+    }
 }
 
 constexpr size_t kColLdsLimit = 160 * 1024 - 1024;      // leave room for the static __shared__ scratch
@@ -467,12 +553,27 @@ hipError_t launch_col_labels(const TemporalArgs& a, bool probe, hipStream_t stre
     const size_t smem = gmem ? 0 : sizeof(int) * (size_t)4 * a.max_slots;
     if (probe) {
         if (!(a.temporal_thresh > 0.f && a.T > 1)) return hipSuccess;
-        if (gmem) hipLaunchKernelGGL((k_col_labels<false, true>), dim3(a.R), dim3(nthreads), smem, stream, a);
-        else hipLaunchKernelGGL((k_col_labels<false, false>), dim3(a.R), dim3(nthreads), smem, stream, a);
+        if (gmem) hipLaunchKernelGGL((k_col_labels<COL_PROBE, true>), dim3(a.R), dim3(nthreads), smem, stream, a);
+        else hipLaunchKernelGGL((k_col_labels<COL_PROBE, false>), dim3(a.R), dim3(nthreads), smem, stream, a);
     } else {
-        if (gmem) hipLaunchKernelGGL((k_col_labels<true, true>), dim3(a.R), dim3(nthreads), smem, stream, a);
-        else hipLaunchKernelGGL((k_col_labels<true, false>), dim3(a.R), dim3(nthreads), smem, stream, a);
+        if (gmem) hipLaunchKernelGGL((k_col_labels<COL_FINAL, true>), dim3(a.R), dim3(nthreads), smem, stream, a);
+        else hipLaunchKernelGGL((k_col_labels<COL_FINAL, false>), dim3(a.R), dim3(nthreads), smem, stream, a);
     }
+    return hipGetLastError();
+}
+
+// One launch for probe + final + rank when every column workgroup is certainly resident at once (R <= 128 CUs'
+// worth, one workgroup per CU at most): the two global agreements become in-kernel grid barriers.
+bool labels_can_fuse(const TemporalArgs& a) { return a.R <= 128 && !a.no_fuse; }
+
+hipError_t launch_labels_fused(const TemporalArgs& a, hipStream_t stream) {
+    const bool gmem = col_labels_use_gmem(a);
+    size_t smem = gmem ? 0 : sizeof(int) * (size_t)4 * a.max_slots;
+    if (smem < sizeof(int) * (size_t)a.T) smem = sizeof(int) * (size_t)a.T;       // the rank phase keeps [T] prefixes there
+    int nthreads = 256;
+    while (nthreads < kColThreads && nthreads * 2 <= a.max_slots) nthreads *= 2;
+    if (gmem) hipLaunchKernelGGL((k_col_labels<COL_FUSED, true>), dim3(a.R), dim3(nthreads), smem, stream, a);
+    else hipLaunchKernelGGL((k_col_labels<COL_FUSED, false>), dim3(a.R), dim3(nthreads), smem, stream, a);
     return hipGetLastError();
 }
 
@@ -510,17 +611,7 @@ __global__ void __launch_bounds__(256) k_rank(TemporalArgs a) {
             ++off;
         }
     }
-    if (t == a.T - 1 && tid == 0) {
-        const int n_out = base + tot;
-        a.counts[STTM_CNT_OUT] = n_out;
-        if (a.counts_host) {
-            // publish the counts straight into pinned host memory: the caller learns N' while k_group_mean still runs
-            for (int i = 0; i < STTM_CNT_SLOTS - 1; ++i)
-                __hip_atomic_store(a.counts_host + i, i == STTM_CNT_OUT ? n_out : a.counts[i], __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(a.counts_host + STTM_CNT_SLOTS - 1, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
+    if (t == a.T - 1 && tid == 0) publish_counts(a, base + tot);
 }
 
 hipError_t launch_rank(const TemporalArgs& a, hipStream_t stream) {
