@@ -111,13 +111,13 @@ size_t carve_all(const Plan& p, int T, int C, int dtype, char* base, Buffers* b)
     o.meta = c.take<uint32_t>(N * 4);
     o.inrm = c.take<double>(N * 8);
     o.rc_list = c.take<int>((size_t)T * p.R * p.rc_stride * 4);
-    o.edges = c.take<int32_t>(nfr * p.ecap * 8);
+    o.edges = c.take<int32_t>(nfr * p.ecap * 4);
     o.edge_cnt = c.take<int32_t>(nfr * 4);
     o.cand_cnt = c.take<int32_t>(nfr * 4);
     o.col_mask = c.take<unsigned long long>((size_t)p.R * 8);
     o.frame_cnt = c.take<int32_t>((size_t)T * 4);
     o.bar = c.take<int32_t>(16);
-    o.colscratch = c.take<int32_t>(N * 16);
+    o.colscratch = c.take<int32_t>(N * 20);
     o.row_info = c.take<int4>(N * 16);
     o.grp_np = c.take<int32_t>(N * 4);
     o.grp_cnt = c.take<int32_t>(N * 4);
@@ -296,6 +296,8 @@ int sttm_quadtree_merge_async(const void* x, int64_t stride_t, int64_t stride_c,
     {
         const char* nf = getenv("STTM_NO_FUSE_LABELS");
         ta.no_fuse = (nf && nf[0] == '1') ? 1 : 0;
+        const char* tk = getenv("STTM_LABEL_TICKS");       // debug: stamps land in the first bytes of feat_out
+        ta.dbg_ticks = (tk && tk[0] == '1') ? reinterpret_cast<long long*>(b.colscratch) : nullptr;
     } ta.colscratch = b.colscratch;
     ta.row_info = b.row_info; ta.grp_np = b.grp_np; ta.grp_cnt = b.grp_cnt; ta.grp_off = b.grp_off; ta.members = b.members;
     ta.counts = counts;
@@ -332,6 +334,15 @@ int sttm_quadtree_merge_async(const void* x, int64_t stride_t, int64_t stride_c,
     prof_mark(4, stream);
     if (g_prof_on) { g_prof_valid = true; g_prof_ran[0] = true; g_prof_ran[1] = pairs; g_prof_ran[2] = true; g_prof_ran[3] = true; }
     return STTM_OK;
+}
+
+// debug helper (not in the public header): byte offset of the column scratch inside the workspace
+size_t sttm_debug_colscratch_offset(int T, int H, int W, int C, int dtype, int root_level) {
+    Plan p;
+    if (make_plan(T, H, W, C, dtype, root_level, &p) < 0) return 0;
+    Buffers b;
+    carve_all(p, T, C, dtype, nullptr, &b);
+    return reinterpret_cast<size_t>(b.colscratch);
 }
 
 int sttm_profile_enable(int on) {

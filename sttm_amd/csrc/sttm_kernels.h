@@ -43,15 +43,16 @@ struct TemporalArgs {
     const int* rc_list;
     int rc_stride;
     // scratch
-    int32_t* edges;           // [(T-1)*R][ecap][2] kept edges (dst = earlier frame, src = later frame), origin rows
+    int32_t* edges;           // [R][T-1][ecap] kept edges, packed column-local slots (dst << 16 | src), dst = earlier frame
     int ecap;
-    int32_t* edge_cnt;        // [(T-1)*R]
-    int32_t* cand_cnt;        // [(T-1)*R]
+    int32_t* edge_cnt;        // [R][T-1]
+    int32_t* cand_cnt;        // [R][T-1]
     unsigned long long* col_mask;   // [R] per-column idempotency history (bit k = idempotent after iteration k+1)
     int32_t* frame_cnt;       // [T] survivors per frame (zeroed by the spatial kernel)
     int32_t* bar;             // [2] grid-barrier counters of the fused label kernel (zeroed by the spatial kernel)
     int no_fuse;              // debug/test: use the three-kernel label path
-    int32_t* colscratch;      // [4*T*H*W] label arrays of columns that do not fit LDS
+    long long* dbg_ticks;     // debug: wall_clock64 stamps of workgroup 0 at phase boundaries (null = off)
+    int32_t* colscratch;      // [5*T*H*W] label arrays of columns that do not fit LDS
     int4* row_info;           // [T*H*W] per output row: origin | leaf bit, member offset, member count, patches
     int32_t* grp_np;          // [T*H*W] by origin row: patches covered by the group
     int32_t* grp_cnt;         // [T*H*W] by origin row; 0 = not a survivor

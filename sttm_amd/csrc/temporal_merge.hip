@@ -31,6 +31,47 @@ __device__ __forceinline__ void st_agent(int32_t* p, int v) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Columns (used by the pair kernel to emit local slot ids and by the label kernels).
+// A column = root cell (I, J) over all T frames.  Local slot of leaf (t, y, x) inside the column:
+//   s = t*A + (y - Y1)*aw + (x - X1),   A = area of the root cell in leaves; monotone in the origin row.
+// ---------------------------------------------------------------------------------------------------
+struct Column {
+    int Y1, X1, ah, aw, A, slots, base;   // base = T * (leaves of the root cells before this one)
+};
+__device__ __forceinline__ void root_extent(const LevelDims& g, int I, int J, int& y1, int& y2, int& x1, int& x2) {
+    int lo_i = I, hi_i = I, lo_j = J, hi_j = J;
+    for (int m = 0; m < g.n_level - 1; ++m) {
+        lo_i = child_start(lo_i, g.h[m + 1]);
+        hi_i = child_start(hi_i, g.h[m + 1]) + child_count(hi_i, g.h[m + 1]) - 1;
+        lo_j = child_start(lo_j, g.w[m + 1]);
+        hi_j = child_start(hi_j, g.w[m + 1]) + child_count(hi_j, g.w[m + 1]) - 1;
+    }
+    y1 = lo_i; y2 = hi_i + 1; x1 = lo_j; x2 = hi_j + 1;
+}
+__device__ __forceinline__ Column make_column(const TemporalArgs& a, int r) {
+    const LevelDims& g = a.dims;
+    const int I = r / g.w[0], J = r % g.w[0];
+    int y1, y2, x1, x2;
+    root_extent(g, I, J, y1, y2, x1, x2);
+    Column c;
+    c.Y1 = y1; c.X1 = x1; c.ah = y2 - y1; c.aw = x2 - x1; c.A = c.ah * c.aw; c.slots = a.T * c.A;
+    // leaves owned by root cells 0..r-1: full root rows above + cells to the left in this root row
+    c.base = a.T * (y1 * a.W + (y2 - y1) * x1);
+    return c;
+}
+__device__ __forceinline__ int slot_to_row(const TemporalArgs& a, const Column& c, int s) {
+    const int t = s / c.A, q = s - t * c.A;
+    const int ly = q / c.aw, lx = q - ly * c.aw;
+    return t * a.H * a.W + (c.Y1 + ly) * a.W + (c.X1 + lx);
+}
+__device__ __forceinline__ int row_to_slot(const TemporalArgs& a, const Column& c, int row) {
+    const int HW = a.H * a.W;
+    const int t = row / HW, rem = row - t * HW;
+    const int y = rem / a.W, x = rem - y * a.W;
+    return t * c.A + (y - c.Y1) * c.aw + (x - c.X1);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // K2: pairs.  One workgroup per (t, root cell): box tests between the node lists of frames t and t+1,
 // then one wave per candidate for the C-long dot product (two candidates in flight per wave).
 // Kept edges go to this workgroup's own slot list -- no global counters.
@@ -47,7 +88,9 @@ __global__ void __launch_bounds__(256) k_pairs(TemporalArgs a) {
     const int* LB = a.rc_list + (int64_t)((t + 1) * R + r) * a.rc_stride;
     const int nA = LA[0], nB = LB[0];
     const int cap = a.ecap;
-    int32_t* my_edges = a.edges + (int64_t)blockIdx.x * cap * 2;
+    const Column col = make_column(a, r);
+    const int64_t cidx = (int64_t)r * (a.T - 1) + t;          // column-major: a column's lists are contiguous
+    int32_t* my_edges = a.edges + cidx * cap;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
     if (tid == 0) { ncand = 0; nkept = 0; }
     __syncthreads();
@@ -101,15 +144,14 @@ __global__ void __launch_bounds__(256) k_pairs(TemporalArgs a) {
             const float sim = (float)((double)dot * a.inrm[rowA] * a.inrm[rowB]);
             if (sim >= a.temporal_thresh) {
                 const int e = atomicAdd(&nkept, 1);
-                my_edges[2 * e] = rowA;
-                my_edges[2 * e + 1] = rowB;
+                my_edges[e] = (int)(((unsigned)row_to_slot(a, col, rowA) << 16) | (unsigned)row_to_slot(a, col, rowB));
             }
         }
     }
     __syncthreads();
     if (tid == 0) {
-        a.edge_cnt[blockIdx.x] = nkept;
-        a.cand_cnt[blockIdx.x] = ncand;
+        a.edge_cnt[cidx] = nkept;
+        a.cand_cnt[cidx] = ncand;
     }
 }
 
@@ -153,47 +195,6 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* lds_wave /*[16]*
     return base + inc - v;
 }
 
-// ---------------------------------------------------------------------------------------------------
-// K3: column labels.
-// A column = root cell (I, J) over all T frames.  Local slot of leaf (t, y, x) inside the column:
-//   s = t*A + (y - Y1)*aw + (x - X1),   A = area of the root cell in leaves; monotone in the origin row.
-// ---------------------------------------------------------------------------------------------------
-struct Column {
-    int Y1, X1, ah, aw, A, slots, base;   // base = T * (leaves of the root cells before this one)
-};
-__device__ __forceinline__ void root_extent(const LevelDims& g, int I, int J, int& y1, int& y2, int& x1, int& x2) {
-    int lo_i = I, hi_i = I, lo_j = J, hi_j = J;
-    for (int m = 0; m < g.n_level - 1; ++m) {
-        lo_i = child_start(lo_i, g.h[m + 1]);
-        hi_i = child_start(hi_i, g.h[m + 1]) + child_count(hi_i, g.h[m + 1]) - 1;
-        lo_j = child_start(lo_j, g.w[m + 1]);
-        hi_j = child_start(hi_j, g.w[m + 1]) + child_count(hi_j, g.w[m + 1]) - 1;
-    }
-    y1 = lo_i; y2 = hi_i + 1; x1 = lo_j; x2 = hi_j + 1;
-}
-__device__ __forceinline__ Column make_column(const TemporalArgs& a, int r) {
-    const LevelDims& g = a.dims;
-    const int I = r / g.w[0], J = r % g.w[0];
-    int y1, y2, x1, x2;
-    root_extent(g, I, J, y1, y2, x1, x2);
-    Column c;
-    c.Y1 = y1; c.X1 = x1; c.ah = y2 - y1; c.aw = x2 - x1; c.A = c.ah * c.aw; c.slots = a.T * c.A;
-    // leaves owned by root cells 0..r-1: full root rows above + cells to the left in this root row
-    c.base = a.T * (y1 * a.W + (y2 - y1) * x1);
-    return c;
-}
-__device__ __forceinline__ int slot_to_row(const TemporalArgs& a, const Column& c, int s) {
-    const int t = s / c.A, q = s - t * c.A;
-    const int ly = q / c.aw, lx = q - ly * c.aw;
-    return t * a.H * a.W + (c.Y1 + ly) * a.W + (c.X1 + lx);
-}
-__device__ __forceinline__ int row_to_slot(const TemporalArgs& a, const Column& c, int row) {
-    const int HW = a.H * a.W;
-    const int t = row / HW, rem = row - t * HW;
-    const int y = rem / a.W, x = rem - y * a.W;
-    return t * c.A + (y - c.Y1) * c.aw + (x - c.X1);
-}
-
 __device__ __forceinline__ int box_area(uint32_t meta, int row, int HW, int W) {
     const int y2 = meta >> 16, x2 = meta & 0xffff;
     const int rem = row % HW;
@@ -217,6 +218,15 @@ template <bool GMEM> __device__ __forceinline__ void cst(int* p, int v) {
 template <bool GMEM> __device__ __forceinline__ void camin(int* p, int v) {
     if constexpr (GMEM) __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else atomicMin(p, v);
+}
+// node areas: uint16 in LDS, int32 (agent scope) in the global-memory fallback
+template <bool GMEM> struct AreaT { typedef uint16_t type; };
+template <> struct AreaT<true> { typedef int type; };
+template <bool GMEM> __device__ __forceinline__ int carea_ld(const typename AreaT<GMEM>::type* p, int i) {
+    if constexpr (GMEM) return ld_agent(p + i); else return p[i];
+}
+template <bool GMEM> __device__ __forceinline__ void carea_st(typename AreaT<GMEM>::type* p, int i, int v) {
+    if constexpr (GMEM) st_agent(p + i, v); else p[i] = (uint16_t)v;
 }
 template <bool GMEM> __device__ __forceinline__ int caadd(int* p, int v) {
     if constexpr (GMEM) return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -257,21 +267,21 @@ __device__ __forceinline__ void column_iteration(int* rep, int* rep2, const int*
     __syncthreads();
 }
 
-// Grid-wide barrier among the (co-resident) column workgroups of the fused kernel: agent-scope release before
-// arriving, relaxed polling, agent-scope acquire after (cdna guide G16).  The spin is bounded: on a timeout the
-// overflow counter is raised (the Python wrapper then fails loudly) instead of hanging the GPU.
+// Grid-wide barrier among the (co-resident) column workgroups of the fused kernel.  The spin is bounded: on a
+// timeout the overflow counter is raised (the Python wrapper then fails loudly) instead of hanging the GPU.
 __device__ __forceinline__ void grid_barrier(int32_t* counter, int target, int32_t* overflow) {
+    // Everything that crosses this barrier is written with agent-scope (write-through, sc1) stores or atomics and read
+    // with agent-scope loads, so no release/acquire cache maintenance is needed: every wave drains its stores, one lane
+    // arrives and polls the counter.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const long long t0 = wall_clock64();                       // 100 MHz
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(1);
             if (wall_clock64() - t0 > 20000000ll) { atomicAdd(overflow, 1); break; }    // 0.2 s
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
 }
@@ -280,24 +290,37 @@ __device__ __forceinline__ void grid_barrier(int32_t* counter, int target, int32
 __device__ __forceinline__ void rank_frame_wave(const TemporalArgs& a, int t, int prefix, int lane) {
     const int HW = a.H * a.W, N = a.T * HW;
     int off = prefix;
-    for (int base = 0; base < HW; base += 64) {
-        const int p = base + lane;
-        const int origin = t * HW + p;
-        const int cnt = p < HW ? a.grp_cnt[origin] : 0;
-        const unsigned long long m = __ballot(cnt > 0);
-        const int mine = off + __popcll(m & ((1ull << lane) - 1ull));
-        if (cnt > 0 && mine < N) {
-            const uint32_t meta = a.meta[origin];
-            const int np = a.grp_np[origin];
-            const int y1 = p / a.W, x1 = p - y1 * a.W;
-            const int y2 = (int)(meta >> 16), x2 = (int)(meta & 0xffff);
-            const bool leaf = (y2 - y1) == 1 && (x2 - x1) == 1;
-            a.row_info[mine] = make_int4(origin | (leaf ? kLeafBit : 0), a.grp_off[origin], cnt, np);
-            a.npatch_out[mine] = np;
-            int32_t* o = a.tlbr_out + (int64_t)mine * 5;
-            o[0] = t; o[1] = y1; o[2] = x1; o[3] = y2; o[4] = x2;
+    constexpr int NB = 4;                                       // chunks of 64 origins loaded together
+    for (int base = 0; base < HW; base += 64 * NB) {
+        int cnt[NB], np[NB], go[NB];
+        uint32_t meta[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {                          // independent loads, issued back to back
+            const int p = base + b * 64 + lane;
+            const bool in = p < HW;
+            const int origin = t * HW + (in ? p : 0);
+            cnt[b] = in ? ld_agent(a.grp_cnt + origin) : 0;
+            np[b] = ld_agent(a.grp_np + origin);
+            go[b] = ld_agent(a.grp_off + origin);
+            meta[b] = a.meta[origin];
         }
-        off += __popcll(m);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int p = base + b * 64 + lane;
+            const unsigned long long m = __ballot(cnt[b] > 0);
+            const int mine = off + __popcll(m & ((1ull << lane) - 1ull));
+            if (cnt[b] > 0 && mine < N) {
+                const int origin = t * HW + p;
+                const int y1 = p / a.W, x1 = p - y1 * a.W;
+                const int y2 = (int)(meta[b] >> 16), x2 = (int)(meta[b] & 0xffff);
+                const bool leaf = (y2 - y1) == 1 && (x2 - x1) == 1;
+                a.row_info[mine] = make_int4(origin | (leaf ? kLeafBit : 0), go[b], cnt[b], np[b]);
+                a.npatch_out[mine] = np[b];
+                int32_t* o = a.tlbr_out + (int64_t)mine * 5;
+                o[0] = t; o[1] = y1; o[2] = x1; o[3] = y2; o[4] = x2;
+            }
+            off += __popcll(m);
+        }
     }
 }
 
@@ -306,13 +329,16 @@ __device__ __forceinline__ void publish_counts(const TemporalArgs& a, int n_out)
     if (a.counts_host) {
         // straight into pinned host memory: the caller learns N' while k_group_mean still runs
         for (int i = 0; i < STTM_CNT_SLOTS - 1; ++i)
-            __hip_atomic_store(a.counts_host + i, i == STTM_CNT_OUT ? n_out : a.counts[i], __ATOMIC_RELAXED,
+            __hip_atomic_store(a.counts_host + i, i == STTM_CNT_OUT ? n_out : ld_agent(a.counts + i), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(a.counts_host + STTM_CNT_SLOTS - 1, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
 enum { COL_PROBE = 0, COL_FINAL = 1, COL_FUSED = 2 };
+
+#define STTM_TICK(n) do { if (a.dbg_ticks && blockIdx.x == 0 && threadIdx.x == 0) a.dbg_ticks[n] = wall_clock64(); } while (0)
+
 
 template <int MODE, bool GMEM>
 __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
@@ -323,15 +349,17 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
     const int r = blockIdx.x, R = a.R;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nwave = nt >> 6;
+    STTM_TICK(0);
     const Column col = make_column(a, r);
     const int slots = col.slots;
     // four arrays of `slots` ints each
-    int* A0 = GMEM ? a.colscratch + (int64_t)4 * col.base : reinterpret_cast<int*>(smem_raw);
+    int* A0 = GMEM ? a.colscratch + (int64_t)5 * col.base : reinterpret_cast<int*>(smem_raw);
     int* rep = A0;                 // labels
     int* rep2 = A0 + slots;        // scatter target during iterations; group sizes afterwards
     int* edges = A0 + 2 * slots;   // [E] packed local (dst << 16 | src) during iterations (E <= 2 * slots)
     int* aux = A0 + 2 * slots;     // afterwards: group offsets / fill cursor
     int* mem = A0 + 3 * slots;     // afterwards: unordered member lists
+    typename AreaT<GMEM>::type* area_l = reinterpret_cast<typename AreaT<GMEM>::type*>(A0 + 4 * slots);   // [slots]
     const bool temporal = a.temporal_thresh > 0.f && a.T > 1;
 
     // ---- gather this column's edges (local slot ids) ------------------------------------------------------
@@ -341,20 +369,25 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
         const int per = (nf + nt - 1) / nt;
         const int lo = tid * per < nf ? tid * per : nf, hi = lo + per < nf ? lo + per : nf;
         int mine = 0;
-        for (int t = lo; t < hi; ++t) mine += a.edge_cnt[t * R + r];
+        const int32_t* ecnt = a.edge_cnt + (int64_t)r * nf;
+        const int32_t* elist = a.edges + (int64_t)r * nf * a.ecap;
+        for (int t = lo; t < hi; ++t) mine += ecnt[t];
         int off = block_exclusive_scan(mine, wsum, &E);
         for (int t = lo; t < hi; ++t) {
-            const int n = a.edge_cnt[t * R + r];
-            const int32_t* src = a.edges + (int64_t)(t * R + r) * a.ecap * 2;
-            for (int k = 0; k < n; ++k) {
-                const unsigned d = (unsigned)row_to_slot(a, col, src[2 * k]), sl = (unsigned)row_to_slot(a, col, src[2 * k + 1]);
-                cst<GMEM>(edges + off + k, (int)((d << 16) | sl));
-            }
+            const int n = ecnt[t];
+            for (int k = 0; k < n; ++k) cst<GMEM>(edges + off + k, elist[(int64_t)t * a.ecap + k]);
             off += n;
         }
     }
+    // node areas (0 = no node starts at this slot): one coalesced pass over meta, reused by every later phase
+    for (int i = tid; i < slots; i += nt) {
+        const int row = slot_to_row(a, col, i);
+        const uint32_t m = a.meta[row];
+        carea_st<GMEM>(area_l, i, m ? box_area(m, row, a.H * a.W, a.W) : 0);
+    }
     for (int i = tid; i < slots; i += nt) { cst<GMEM>(rep + i, i); cst<GMEM>(rep2 + i, i); }
     __syncthreads();
+    STTM_TICK(1);
 
     int probe_iters = 0;
     if (MODE != COL_FINAL && temporal) {
@@ -379,7 +412,9 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
         probe_iters = it;
     }
     if constexpr (MODE == COL_PROBE) return;
+    STTM_TICK(2);
     if constexpr (MODE == COL_FUSED) grid_barrier(a.bar + 0, R, a.counts + STTM_CNT_OVERFLOW);
+    STTM_TICK(3);
     {
         // ---- FINAL: K = first iteration after which EVERY column is idempotent; labels after exactly K iterations --
         int K = 0;
@@ -403,6 +438,7 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
                 for (int it = 0; it < K; ++it) column_iteration<GMEM>(rep, rep2, edges, E, slots, flags);
             }
         }
+        STTM_TICK(4);
         // from here: rep = final labels; rep2, the edge array and `mem` are free
         int* gcnt = rep2;
         const int HW = a.H * a.W;
@@ -410,9 +446,10 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
         __syncthreads();
         int nodes = 0;
         for (int i = tid; i < slots; i += nt) {
-            if (a.meta[slot_to_row(a, col, i)] != 0u) { caadd<GMEM>(gcnt + cld<GMEM>(rep + i), 1); ++nodes; }
+            if (carea_ld<GMEM>(area_l, i)) { caadd<GMEM>(gcnt + cld<GMEM>(rep + i), 1); ++nodes; }
         }
         __syncthreads();
+        STTM_TICK(5);
         // offsets of the groups inside this column's slice of `members` (exclusive scan over slots)
         {
             const int per = (slots + nt - 1) / nt;
@@ -425,12 +462,13 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
                 const int n = cld<GMEM>(gcnt + i);
                 cst<GMEM>(aux + i, off);
                 const int row = slot_to_row(a, col, i);
-                a.grp_off[row] = col.base + off;
-                a.grp_cnt[row] = n;                   // 0 for non-survivors: k_rank keys on this
+                st_agent(a.grp_off + row, col.base + off);
+                st_agent(a.grp_cnt + row, n);         // 0 for non-survivors: the rank phase keys on this
                 off += n;
             }
         }
         __syncthreads();
+        STTM_TICK(6);
         // survivors per frame -> frame_cnt (one atomic per (frame, column))
         if (col.A <= 64) {
             for (int t = tid; t < a.T; t += nt) {
@@ -447,9 +485,10 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
                 if (lane == 0 && c) atomicAdd(a.frame_cnt + t, c);
             }
         }
+        STTM_TICK(7);
         // unordered fill (cursor = aux), then order every multi-member group ascending and publish global rows
         for (int i = tid; i < slots; i += nt) {
-            if (a.meta[slot_to_row(a, col, i)] != 0u) {
+            if (carea_ld<GMEM>(area_l, i)) {
                 const int pos = caadd<GMEM>(aux + cld<GMEM>(rep + i), 1);
                 cst<GMEM>(mem + pos, i);
             }
@@ -466,9 +505,9 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
             const int o = cld<GMEM>(aux + i) - n;          // the cursor ended at offset + n
             const int self_row = slot_to_row(a, col, i);
             if (n == 1) {
-                const int ar = box_area(a.meta[self_row], self_row, HW, a.W);
-                out[o] = self_row | (ar == 1 ? kLeafBit : 0);
-                a.grp_np[self_row] = ar;
+                const int ar = carea_ld<GMEM>(area_l, i);
+                st_agent(out + o, self_row | (ar == 1 ? kLeafBit : 0));
+                st_agent(a.grp_np + self_row, ar);
                 continue;
             }
             if (n > kSmall) { flags[0] = 1; continue; }
@@ -478,11 +517,11 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
                 int rk = 0;
                 for (int j = 0; j < n; ++j) rk += cld<GMEM>(mem + o + j) < v ? 1 : 0;
                 const int vr = slot_to_row(a, col, v);
-                const int ar = box_area(a.meta[vr], vr, HW, a.W);
+                const int ar = carea_ld<GMEM>(area_l, v);
                 patches += ar;
-                out[o + rk] = vr | (ar == 1 ? kLeafBit : 0);
+                st_agent(out + o + rk, vr | (ar == 1 ? kLeafBit : 0));
             }
-            a.grp_np[self_row] = patches;
+            st_agent(a.grp_np + self_row, patches);
         }
         __syncthreads();
         if (flags[0]) {
@@ -496,19 +535,20 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
                     int rk = 0;
                     for (int j = 0; j < n; ++j) rk += cld<GMEM>(mem + o + j) < v ? 1 : 0;
                     const int vr = slot_to_row(a, col, v);
-                    const int ar = box_area(a.meta[vr], vr, HW, a.W);
+                    const int ar = carea_ld<GMEM>(area_l, v);
                     patches += ar;
-                    out[o + rk] = vr | (ar == 1 ? kLeafBit : 0);
+                    st_agent(out + o + rk, vr | (ar == 1 ? kLeafBit : 0));
                 }
 #pragma unroll
                 for (int d = 32; d >= 1; d >>= 1) patches += __shfl_xor(patches, d, 64);
-                if (lane == 0) a.grp_np[slot_to_row(a, col, i)] = patches;
+                if (lane == 0) st_agent(a.grp_np + slot_to_row(a, col, i), patches);
             }
         }
+        STTM_TICK(8);
         // bookkeeping counters: one atomic per column and slot
         if (temporal) {
             int cand = 0;
-            for (int t = tid; t < a.T - 1; t += nt) cand += a.cand_cnt[t * R + r];
+            for (int t = tid; t < a.T - 1; t += nt) cand += a.cand_cnt[(int64_t)r * (a.T - 1) + t];
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) cand += __shfl_xor(cand, d, 64);
             if (lane == 0 && cand) atomicAdd(a.counts + STTM_CNT_CANDIDATES, cand);
@@ -523,34 +563,38 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
     }
     if constexpr (MODE == COL_FUSED) {
         // ---- RANK: every column has published its groups and per-frame survivor counts ------------------------
+        STTM_TICK(9);
         grid_barrier(a.bar + 1, R, a.counts + STTM_CNT_OVERFLOW);
+        STTM_TICK(10);
         int* fpre = reinterpret_cast<int*>(smem_raw);          // [T] exclusive prefix of frame_cnt (LDS is free now)
         int total = 0;
         {
             const int per = (a.T + nt - 1) / nt;
             const int lo = tid * per < a.T ? tid * per : a.T, hi = lo + per < a.T ? lo + per : a.T;
             int mine = 0;
-            for (int t = lo; t < hi; ++t) mine += a.frame_cnt[t];
+            for (int t = lo; t < hi; ++t) mine += ld_agent(a.frame_cnt + t);
             int off = block_exclusive_scan(mine, wsum, &total);
-            for (int t = lo; t < hi; ++t) { fpre[t] = off; off += a.frame_cnt[t]; }
+            for (int t = lo; t < hi; ++t) { fpre[t] = off; off += ld_agent(a.frame_cnt + t); }
         }
         __syncthreads();
         for (int t = r * nwave + wave; t < a.T; t += R * nwave) rank_frame_wave(a, t, fpre[t], lane);
+        STTM_TICK(11);
         if (r == 0 && tid == 0) publish_counts(a, total);
+        STTM_TICK(12);
     }
 }
 
 constexpr size_t kColLdsLimit = 160 * 1024 - 1024;      // leave room for the static __shared__ scratch
 
 bool col_labels_use_gmem(const TemporalArgs& a) {
-    return a.force_gmem || sizeof(int) * (size_t)4 * a.max_slots > kColLdsLimit;
+    return a.force_gmem || (size_t)18 * a.max_slots > kColLdsLimit;
 }
 
 hipError_t launch_col_labels(const TemporalArgs& a, bool probe, hipStream_t stream) {
     const bool gmem = col_labels_use_gmem(a);
     int nthreads = 256;
     while (nthreads < kColThreads && nthreads * 2 <= a.max_slots) nthreads *= 2;
-    const size_t smem = gmem ? 0 : sizeof(int) * (size_t)4 * a.max_slots;
+    const size_t smem = gmem ? 0 : (size_t)18 * a.max_slots;
     if (probe) {
         if (!(a.temporal_thresh > 0.f && a.T > 1)) return hipSuccess;
         if (gmem) hipLaunchKernelGGL((k_col_labels<COL_PROBE, true>), dim3(a.R), dim3(nthreads), smem, stream, a);
@@ -568,7 +612,7 @@ bool labels_can_fuse(const TemporalArgs& a) { return a.R <= 128 && !a.no_fuse; }
 
 hipError_t launch_labels_fused(const TemporalArgs& a, hipStream_t stream) {
     const bool gmem = col_labels_use_gmem(a);
-    size_t smem = gmem ? 0 : sizeof(int) * (size_t)4 * a.max_slots;
+    size_t smem = gmem ? 0 : (size_t)18 * a.max_slots;
     if (smem < sizeof(int) * (size_t)a.T) smem = sizeof(int) * (size_t)a.T;       // the rank phase keeps [T] prefixes there
     int nthreads = 256;
     while (nthreads < kColThreads && nthreads * 2 <= a.max_slots) nthreads *= 2;
