@@ -297,6 +297,8 @@ int sttm_quadtree_merge_async(const void* x, int64_t stride_t, int64_t stride_c,
         const char* nf = getenv("STTM_NO_FUSE_LABELS");
         ta.no_fuse = (nf && nf[0] == '1') ? 1 : 0;
         const char* tk = getenv("STTM_LABEL_TICKS");       // debug: stamps land in the first bytes of feat_out
+        const char* tw = getenv("STTM_LABEL_TICKS_WG");
+        ta.dbg_wg = tw ? atoi(tw) : 0;
         ta.dbg_ticks = (tk && tk[0] == '1') ? reinterpret_cast<long long*>(b.colscratch) : nullptr;
     } ta.colscratch = b.colscratch;
     ta.row_info = b.row_info; ta.grp_np = b.grp_np; ta.grp_cnt = b.grp_cnt; ta.grp_off = b.grp_off; ta.members = b.members;

@@ -51,6 +51,7 @@ struct TemporalArgs {
     int32_t* frame_cnt;       // [T] survivors per frame (zeroed by the spatial kernel)
     int32_t* bar;             // [2] grid-barrier counters of the fused label kernel (zeroed by the spatial kernel)
     int no_fuse;              // debug/test: use the three-kernel label path
+    int dbg_wg;               // debug: which workgroup stamps
     long long* dbg_ticks;     // debug: wall_clock64 stamps of workgroup 0 at phase boundaries (null = off)
     int32_t* colscratch;      // [5*T*H*W] label arrays of columns that do not fit LDS
     int4* row_info;           // [T*H*W] per output row: origin | leaf bit, member offset, member count, patches

@@ -149,6 +149,7 @@ __global__ void __launch_bounds__(256) k_pairs(TemporalArgs a) {
         }
     }
     __syncthreads();
+    for (int e = nkept + tid; e < cap; e += blockDim.x) my_edges[e] = -1;      // unused entries: the reader scans all `cap`
     if (tid == 0) {
         a.edge_cnt[cidx] = nkept;
         a.cand_cnt[cidx] = ncand;
@@ -337,7 +338,7 @@ __device__ __forceinline__ void publish_counts(const TemporalArgs& a, int n_out)
 
 enum { COL_PROBE = 0, COL_FINAL = 1, COL_FUSED = 2 };
 
-#define STTM_TICK(n) do { if (a.dbg_ticks && blockIdx.x == 0 && threadIdx.x == 0) a.dbg_ticks[n] = wall_clock64(); } while (0)
+#define STTM_TICK(n) do { if (a.dbg_ticks && blockIdx.x == a.dbg_wg && threadIdx.x == 0) a.dbg_ticks[n] = wall_clock64(); } while (0)
 
 
 template <int MODE, bool GMEM>
@@ -364,26 +365,45 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
 
     // ---- gather this column's edges (local slot ids) ------------------------------------------------------
     int E = 0;
-    if (temporal) {
-        const int nf = a.T - 1;
-        const int per = (nf + nt - 1) / nt;
-        const int lo = tid * per < nf ? tid * per : nf, hi = lo + per < nf ? lo + per : nf;
-        int mine = 0;
-        const int32_t* ecnt = a.edge_cnt + (int64_t)r * nf;
-        const int32_t* elist = a.edges + (int64_t)r * nf * a.ecap;
-        for (int t = lo; t < hi; ++t) mine += ecnt[t];
-        int off = block_exclusive_scan(mine, wsum, &E);
-        for (int t = lo; t < hi; ++t) {
-            const int n = ecnt[t];
-            for (int k = 0; k < n; ++k) cst<GMEM>(edges + off + k, elist[(int64_t)t * a.ecap + k]);
-            off += n;
+    // node areas first: their loads fly while the edge lists are fetched
+    uint32_t my_meta[4];
+    int my_row[4];
+    const bool few = slots <= 4 * nt;
+    if (few) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = tid + k * nt;
+            my_row[k] = i < slots ? slot_to_row(a, col, i) : 0;
+            my_meta[k] = i < slots ? a.meta[my_row[k]] : 0u;
         }
     }
+    if (temporal) {
+        const int nf = a.T - 1;
+        const int32_t* elist = a.edges + (int64_t)r * nf * a.ecap;
+        const int total = nf * a.ecap;
+        if (tid == 0) flags[0] = 0;
+        __syncthreads();
+        for (int j = tid; j < total; j += nt) {
+            const int pr = elist[j];
+            if (pr != -1) cst<GMEM>(edges + atomicAdd(&flags[0], 1), pr);
+        }
+        __syncthreads();
+        E = flags[0];
+        __syncthreads();
+    }
     // node areas (0 = no node starts at this slot): one coalesced pass over meta, reused by every later phase
-    for (int i = tid; i < slots; i += nt) {
-        const int row = slot_to_row(a, col, i);
-        const uint32_t m = a.meta[row];
-        carea_st<GMEM>(area_l, i, m ? box_area(m, row, a.H * a.W, a.W) : 0);
+    if (few) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = tid + k * nt;
+            if (i < slots) carea_st<GMEM>(area_l, i, my_meta[k] ? box_area(my_meta[k], my_row[k], a.H * a.W, a.W) : 0);
+        }
+    } else {
+        for (int i = tid; i < slots; i += nt) {
+            const int row = slot_to_row(a, col, i);
+            const uint32_t m = a.meta[row];
+            carea_st<GMEM>(area_l, i, m ? box_area(m, row, a.H * a.W, a.W) : 0);
+        }
     }
     for (int i = tid; i < slots; i += nt) { cst<GMEM>(rep + i, i); cst<GMEM>(rep2 + i, i); }
     __syncthreads();
