@@ -13,8 +13,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsttm_hip.so")
-SOURCES = ["quadtree_spatial.hip", "temporal_merge.hip", "tome.hip", "api.hip"]
-HEADERS = ["sttm_common.h", "sttm_kernels.h", os.path.join("..", "..", "include", "sttm_hip.h")]
+SOURCES = ["quadtree_spatial.hip", "spatial_f32.hip", "spatial_bf16.hip", "spatial_f16.hip", "spatial_f32_head.hip",
+           "spatial_bf16_head.hip", "spatial_f16_head.hip", "temporal_merge.hip", "tome.hip", "api.hip"]
+HEADERS = ["sttm_common.h", "sttm_kernels.h", "quadtree_spatial.inc", os.path.join("..", "..", "include", "sttm_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -50,7 +51,7 @@ def build(force=False, verbose=False, extra_flags=()):
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
         if verbose and r.stderr:
             print(r.stderr)
-    with concurrent.futures.ThreadPoolExecutor(max_workers=4) as ex:
+    with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
         run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])

@@ -226,7 +226,7 @@ int sttm_quadtree_merge_async(const void* x, int64_t stride_t, int64_t stride_c,
     if (stride_c != 1) return fail(STTM_ERR_ARG, "channel stride must be 1 (channels-last view); got %lld", (long long)stride_c);
     if (H > 255 || W > 255) return fail(STTM_ERR_UNSUPPORTED, "token grids larger than 255 per side are not supported");
     if ((int64_t)T * H * W >= (1ll << 31) / 8) return fail(STTM_ERR_UNSUPPORTED, "too many tokens");
-    if (head_dim != 0) return fail(STTM_ERR_UNSUPPORTED, "per-head similarity (head_dim) is not implemented on the device path yet");
+    if (head_dim < 0 || (head_dim > 0 && C % head_dim)) return fail(STTM_ERR_ARG, "head_dim %d does not divide C = %d", head_dim, C);
     Plan p;
     const int D = make_plan(T, H, W, C, dtype, root_level, &p);
     if (D < 0) return D;
@@ -244,6 +244,15 @@ int sttm_quadtree_merge_async(const void* x, int64_t stride_t, int64_t stride_c,
 
     if (p.max_slots > 65536)
         return fail(STTM_ERR_UNSUPPORTED, "T * (root-cell area) = %d exceeds 65536 label slots per column", p.max_slots);
+    int n_head = 0, head_lanes = 0;
+    if (head_dim > 0) {
+        // one head = head_dim / vec adjacent lanes: must be a power of two that fits a wave
+        if (head_dim % vec) return fail(STTM_ERR_UNSUPPORTED, "head_dim %d is not a multiple of the %d-wide channel pack", head_dim, vec);
+        head_lanes = head_dim / vec;
+        if (head_lanes > 64 || (head_lanes & (head_lanes - 1)))
+            return fail(STTM_ERR_UNSUPPORTED, "head_dim / pack width = %d lanes: need a power of two <= 64", head_lanes);
+        n_head = C / head_dim;
+    }
     Buffers b;
     carve_all(p, T, C, dtype, reinterpret_cast<char*>(workspace), &b);
     sttm::SpatialArgs sa;
@@ -263,6 +272,7 @@ int sttm_quadtree_merge_async(const void* x, int64_t stride_t, int64_t stride_c,
         sa.thr_lo_sq = lo * fabs(lo);
     }
     sa.sum_mode = weighted_avg ? 1 : 0;
+    sa.n_head = n_head; sa.head_lanes = head_lanes;
     // dense [T*H*W, C] input: the rows of 1x1 nodes are read from x by the later kernels instead of being copied to S
     const bool dense = stride_w == C && stride_h == (int64_t)W * C && stride_t == (int64_t)H * W * C;
     sa.leaves_in_x = dense ? 1 : 0;
@@ -285,6 +295,7 @@ int sttm_quadtree_merge_async(const void* x, int64_t stride_t, int64_t stride_c,
     ta.dtype = dtype; ta.vec = vec;
     ta.temporal_thresh = temporal_thresh;
     ta.weighted_avg = weighted_avg ? 1 : 0;
+    ta.n_head = n_head; ta.head_lanes = head_lanes;
     ta.max_slots = p.max_slots;
     {
         const char* fg = getenv("STTM_FORCE_GMEM_LABELS");

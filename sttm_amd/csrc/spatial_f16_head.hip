@@ -1,0 +1,6 @@
+// Explicit instantiation of the spatial kernels for one (dtype, per-head) combination.
+#include "quadtree_spatial.inc"
+
+namespace sttm {
+template hipError_t launch_spatial_t<f16_t, true>(const SpatialArgs&, int, int, hipStream_t);
+}  // namespace sttm

@@ -13,6 +13,8 @@ struct SpatialArgs {
     float threshold;
     double thr_lo_sq;         // lo*|lo| with lo = smallest real that rounds (fp32, RNE) to >= threshold
     int sum_mode;             // weighted_avg: sum-pool pyramid
+    int n_head;               // 0 = whole-vector cosine; > 0 = per-head cosine averaged over n_head heads
+    int head_lanes;           // head_dim / vec: adjacent lanes that own one head (power of two <= 64)
     int pipeline;             // opt-in: persistent double-buffered 3-level kernel (measured slower on MI355X)
     int dbg_mode;             // ablation (sttm_debug_spatial_ms only): 1 = stop after the statistics, 2 = loads + pooling only
     int leaves_in_x;          // x is a dense [T*H*W, C] matrix: 1x1 nodes are NOT copied to S (consumers read x)
@@ -33,6 +35,7 @@ struct TemporalArgs {
     LevelDims dims;
     int dtype, vec;
     float temporal_thresh;    // <= 0: no edges (labels stay the identity)
+    int n_head, head_lanes;   // per-head cosine in the pair filter (0 = whole vector)
     int weighted_avg;
     int max_slots;            // T * (largest root-cell area in leaves)
     int force_gmem;           // debug/test: run the label kernels on the global-memory path

@@ -117,6 +117,34 @@ __global__ void __launch_bounds__(256) k_pairs(TemporalArgs a) {
         const bool leaf = ((b >> 8) & 255) - (b >> 24) == 1 && (b & 255) - ((b >> 16) & 255) == 1;
         return (leaf && a.xrows) ? a.xrows : a.S;
     };
+    if (a.n_head > 0) {
+        // per-head cosine, averaged over heads (quadtree_temporal_merger.py:65-68): G adjacent lanes own one head
+        const int G = a.head_lanes;
+        for (int c = wave; c < nc; c += nwave) {
+            const int k0 = cand[c];
+            const int rowA = row_of(LA, k0 >> 16, t), rowB = row_of(LB, k0 & 0xffff, t + 1);
+            const void* sA = src_of(LA, k0 >> 16); const void* sB = src_of(LB, k0 & 0xffff);
+            float acc = 0.f;
+            for (int base = 0; base < a.C; base += 64 * VEC) {
+                const int c0 = base + lane * VEC;
+                float d = 0.f, na = 0.f, nb = 0.f;
+                if (c0 < a.C) {
+                    const Pack<T, VEC> pa = load_pack<T, VEC>(sA, (int64_t)rowA * a.C + c0);
+                    const Pack<T, VEC> pb = load_pack<T, VEC>(sB, (int64_t)rowB * a.C + c0);
+                    d = dot_pack(pa, pb); na = dot_pack(pa, pa); nb = dot_pack(pb, pb);
+                }
+                for (int m = 1; m < G; m <<= 1) {
+                    d += __shfl_xor(d, m, 64); na += __shfl_xor(na, m, 64); nb += __shfl_xor(nb, m, 64);
+                }
+                if ((lane & (G - 1)) == 0 && c0 < a.C) acc += d / ((sqrtf(na) + 1e-8f) * (sqrtf(nb) + 1e-8f));
+            }
+            acc = wave_sum(acc);
+            if (lane == 0 && acc / (float)a.n_head >= a.temporal_thresh) {
+                const int e = atomicAdd(&nkept, 1);
+                my_edges[e] = (int)(((unsigned)row_to_slot(a, col, rowA) << 16) | (unsigned)row_to_slot(a, col, rowB));
+            }
+        }
+    } else
     for (int c = wave; c < nc; c += 2 * nwave) {
         const int c2 = c + nwave;
         const bool two = c2 < nc;

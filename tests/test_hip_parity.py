@@ -38,7 +38,7 @@ def _check(out, exp, tol, what=""):
 
 def _supported(meta):
     kw = meta["kw"]
-    return not kw.get("slow_ver") and kw.get("head_dim") is None
+    return not kw.get("slow_ver")
 
 
 GOLDEN = [p for p in case_paths(["sp_", "st_"])]
@@ -98,6 +98,19 @@ def test_against_oracle(case):
     exp = O.get_quadtree_features(x, thr, tthr, root, weighted)
     out = get_quadtree_features(x.to(_dev()), thr, tthr, root, weighted)
     _check(out, exp, FP32_TOL if dtype == torch.float32 else BF16_TOL, str(case[:5]))
+
+
+@pytest.mark.parametrize("T,C,H,W,hd,dtype,root", [(6, 512, 14, 14, 64, torch.float32, 1), (4, 3584, 14, 14, 128, torch.bfloat16, 1),
+                                                       (4, 256, 20, 36, 32, torch.float32, 1), (3, 256, 27, 27, 64, torch.float32, 0)])
+def test_per_head_similarity_against_oracle(T, C, H, W, hd, dtype, root):
+    """sim_per_head: head_dim = the decoder's head size (quadtree_attn_monkey_patch.py:99)."""
+    from oracle import sttm_oracle as O
+    from sttm_amd import get_quadtree_features
+    from sttm_amd.synth import synth_video
+    x = synth_video(T, C, H, W, seed=70 + T, dtype=dtype)
+    exp = O.get_quadtree_features(x, 0.85, 0.55, root, head_dim=hd)
+    out = get_quadtree_features(x.to(_dev()), 0.85, 0.55, root, head_dim=hd)
+    _check(out, exp, FP32_TOL if dtype == torch.float32 else BF16_TOL, f"head_dim={hd}")
 
 
 def test_nchw_contiguous_input_is_accepted():
