@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STTM_ABI_VERSION 1
+#define STTM_ABI_VERSION 2
 
 #define STTM_F32 0
 #define STTM_BF16 1
@@ -76,6 +76,8 @@ size_t sttm_quadtree_workspace_bytes(int T, int H, int W, int C, int dtype, int 
  *   root_level            index into the level-size list, negatives allowed (`root_level`)
  *   weighted_avg          0/1: sum-pool pyramid + divide by patch count (`weighted_avg`)
  *   head_dim              0 = whole-vector cosine; > 0 = per-head cosine, mean over heads (`head_dim`)
+ *   slow_ver              0/1: cross_frame_node_merging_slow -- per frame pair, sort kept edges by similarity and drop
+ *                         adjacent duplicates of the same src (quadtree_temporal_merger.py:75-121)
  *   workspace             >= sttm_quadtree_workspace_bytes(...) bytes, 256-byte aligned
  *   feat_out              [T*H*W, C] worst case, dtype of x;  rows [0, N') are valid on return
  *   npatch_out            [T*H*W] int32
@@ -85,7 +87,7 @@ size_t sttm_quadtree_workspace_bytes(int T, int H, int W, int C, int dtype, int 
  */
 int sttm_quadtree_merge(const void* x, int64_t stride_t, int64_t stride_c, int64_t stride_h, int64_t stride_w,
                         int T, int C, int H, int W, int dtype,
-                        float threshold, float temporal_thresh, int root_level, int weighted_avg, int head_dim,
+                        float threshold, float temporal_thresh, int root_level, int weighted_avg, int head_dim, int slow_ver,
                         void* workspace, size_t workspace_bytes,
                         void* feat_out, int32_t* npatch_out, int32_t* tlbr_out, int32_t* counts,
                         void* stream);
@@ -100,7 +102,7 @@ int sttm_quadtree_merge(const void* x, int64_t stride_t, int64_t stride_c, int64
  */
 int sttm_quadtree_merge_async(const void* x, int64_t stride_t, int64_t stride_c, int64_t stride_h, int64_t stride_w,
                               int T, int C, int H, int W, int dtype,
-                              float threshold, float temporal_thresh, int root_level, int weighted_avg, int head_dim,
+                              float threshold, float temporal_thresh, int root_level, int weighted_avg, int head_dim, int slow_ver,
                               void* workspace, size_t workspace_bytes,
                               void* feat_out, int32_t* npatch_out, int32_t* tlbr_out, int32_t* counts,
                               int32_t* counts_host, int seq, void* stream);

@@ -20,9 +20,9 @@ SIGNATURES = {
     "sttm_last_error": (ctypes.c_char_p, []),
     "sttm_quadtree_num_levels": (_i, [_i, _i, _i]),
     "sttm_quadtree_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
-    "sttm_quadtree_merge": (_i, [_vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _f, _i, _i, _i,
+    "sttm_quadtree_merge": (_i, [_vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _f, _i, _i, _i, _i,
                                  _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
-    "sttm_quadtree_merge_async": (_i, [_vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _f, _i, _i, _i,
+    "sttm_quadtree_merge_async": (_i, [_vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _f, _i, _i, _i, _i,
                                        _vp, _sz, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "sttm_wait_counts": (_i, [_vp, _i, _i]),
     "sttm_profile_enable": (_i, [_i]),
@@ -49,7 +49,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.sttm_abi_version() != 1:
+    if lib.sttm_abi_version() != 2:
         raise RuntimeError("libsttm_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -97,7 +97,7 @@ void root_extent_host(const sttm::LevelDims& g, int I, int J, int* ah, int* aw) 
 
 struct Buffers {
     char* S; uint32_t* meta; double* inrm; int* rc_list;
-    int32_t *edges, *edge_cnt, *cand_cnt; unsigned long long* col_mask; int32_t *frame_cnt, *bar, *colscratch;
+    int32_t *edges; float* edge_sim; int32_t *edge_cnt, *cand_cnt; unsigned long long* col_mask; int32_t *frame_cnt, *bar, *colscratch;
     int4* row_info; int32_t *grp_np, *grp_cnt, *grp_off, *members;
 };
 
@@ -112,6 +112,7 @@ size_t carve_all(const Plan& p, int T, int C, int dtype, char* base, Buffers* b)
     o.inrm = c.take<double>(N * 8);
     o.rc_list = c.take<int>((size_t)T * p.R * p.rc_stride * 4);
     o.edges = c.take<int32_t>(nfr * p.ecap * 4);
+    o.edge_sim = c.take<float>(nfr * p.ecap * 4);
     o.edge_cnt = c.take<int32_t>(nfr * 4);
     o.cand_cnt = c.take<int32_t>(nfr * 4);
     o.col_mask = c.take<unsigned long long>((size_t)p.R * 8);
@@ -188,12 +189,12 @@ size_t sttm_quadtree_workspace_bytes(int T, int H, int W, int C, int dtype, int 
 
 int sttm_quadtree_merge(const void* x, int64_t stride_t, int64_t stride_c, int64_t stride_h, int64_t stride_w,
                         int T, int C, int H, int W, int dtype,
-                        float threshold, float temporal_thresh, int root_level, int weighted_avg, int head_dim,
+                        float threshold, float temporal_thresh, int root_level, int weighted_avg, int head_dim, int slow_ver,
                         void* workspace, size_t workspace_bytes,
                         void* feat_out, int32_t* npatch_out, int32_t* tlbr_out, int32_t* counts,
                         void* stream_) {
     return sttm_quadtree_merge_async(x, stride_t, stride_c, stride_h, stride_w, T, C, H, W, dtype, threshold, temporal_thresh,
-                                     root_level, weighted_avg, head_dim, workspace, workspace_bytes, feat_out, npatch_out,
+                                     root_level, weighted_avg, head_dim, slow_ver, workspace, workspace_bytes, feat_out, npatch_out,
                                      tlbr_out, counts, nullptr, 0, stream_);
 }
 
@@ -215,7 +216,7 @@ int sttm_wait_counts(const int32_t* counts_host, int seq, int timeout_us) {
 
 int sttm_quadtree_merge_async(const void* x, int64_t stride_t, int64_t stride_c, int64_t stride_h, int64_t stride_w,
                               int T, int C, int H, int W, int dtype,
-                              float threshold, float temporal_thresh, int root_level, int weighted_avg, int head_dim,
+                              float threshold, float temporal_thresh, int root_level, int weighted_avg, int head_dim, int slow_ver,
                               void* workspace, size_t workspace_bytes,
                               void* feat_out, int32_t* npatch_out, int32_t* tlbr_out, int32_t* counts,
                               int32_t* counts_host, int seq, void* stream_) {
@@ -295,14 +296,17 @@ int sttm_quadtree_merge_async(const void* x, int64_t stride_t, int64_t stride_c,
     ta.dtype = dtype; ta.vec = vec;
     ta.temporal_thresh = temporal_thresh;
     ta.weighted_avg = weighted_avg ? 1 : 0;
-    ta.n_head = n_head; ta.head_lanes = head_lanes;
+    // slow_ver has no per-head variant upstream (cross_frame_node_merging_slow ignores head_dim)
+    ta.n_head = slow_ver ? 0 : n_head; ta.head_lanes = slow_ver ? 0 : head_lanes;
+    ta.inline_norms = (slow_ver && n_head > 0) ? 1 : 0;
+    ta.slow_ver = slow_ver ? 1 : 0;
     ta.max_slots = p.max_slots;
     {
         const char* fg = getenv("STTM_FORCE_GMEM_LABELS");
         ta.force_gmem = (fg && fg[0] == '1') ? 1 : 0;
     }
     ta.S = b.S; ta.xrows = dense ? x : nullptr; ta.meta = b.meta; ta.inrm = b.inrm; ta.rc_list = b.rc_list; ta.rc_stride = p.rc_stride;
-    ta.edges = b.edges; ta.ecap = p.ecap; ta.edge_cnt = b.edge_cnt; ta.cand_cnt = b.cand_cnt;
+    ta.edges = b.edges; ta.edge_sim = slow_ver ? b.edge_sim : nullptr; ta.ecap = p.ecap; ta.edge_cnt = b.edge_cnt; ta.cand_cnt = b.cand_cnt;
     ta.col_mask = b.col_mask; ta.frame_cnt = b.frame_cnt; ta.bar = b.bar;
     {
         const char* nf = getenv("STTM_NO_FUSE_LABELS");
@@ -332,6 +336,10 @@ int sttm_quadtree_merge_async(const void* x, int64_t stride_t, int64_t stride_c,
     if (pairs) {
         if ((e = sttm::launch_pairs(ta, stream)) != hipSuccess)
             return fail(STTM_ERR_LAUNCH, "pairs kernel: %s", hipGetErrorString(e));
+    }
+    if (pairs && slow_ver) {
+        if ((e = sttm::launch_slow_filter(ta, stream)) != hipSuccess)
+            return fail(e == hipErrorInvalidValue ? STTM_ERR_UNSUPPORTED : STTM_ERR_LAUNCH, "slow_ver filter kernel: %s", hipGetErrorString(e));
     }
     prof_mark(2, stream);
     if (sttm::labels_can_fuse(ta)) {

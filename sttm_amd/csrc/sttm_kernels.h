@@ -36,6 +36,8 @@ struct TemporalArgs {
     int dtype, vec;
     float temporal_thresh;    // <= 0: no edges (labels stay the identity)
     int n_head, head_lanes;   // per-head cosine in the pair filter (0 = whole vector)
+    int inline_norms;         // the pair kernel computes |x| itself (spatial stage ran per-head, pair filter does not)
+    int slow_ver;
     int weighted_avg;
     int max_slots;            // T * (largest root-cell area in leaves)
     int force_gmem;           // debug/test: run the label kernels on the global-memory path
@@ -48,6 +50,7 @@ struct TemporalArgs {
     // scratch
     int32_t* edges;           // [R][T-1][ecap] kept edges, packed column-local slots (dst << 16 | src), dst = earlier frame
     int ecap;
+    float* edge_sim;          // [R][T-1][ecap] similarity of each kept edge (slow_ver only, else null)
     int32_t* edge_cnt;        // [R][T-1]
     int32_t* cand_cnt;        // [R][T-1]
     unsigned long long* col_mask;   // [R] per-column idempotency history (bit k = idempotent after iteration k+1)
@@ -71,6 +74,7 @@ struct TemporalArgs {
     int32_t* tlbr_out;
 };
 hipError_t launch_pairs(const TemporalArgs& a, hipStream_t stream);
+hipError_t launch_slow_filter(const TemporalArgs& a, hipStream_t stream);
 hipError_t launch_col_labels(const TemporalArgs& a, bool probe, hipStream_t stream);
 hipError_t launch_rank(const TemporalArgs& a, hipStream_t stream);
 bool labels_can_fuse(const TemporalArgs& a);

@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(256) k_pairs(TemporalArgs a) {
         const int rowA1 = row_of(LA, k1 >> 16, t), rowB1 = row_of(LB, k1 & 0xffff, t + 1);
         const void* sA0 = src_of(LA, k0 >> 16); const void* sB0 = src_of(LB, k0 & 0xffff);
         const void* sA1 = src_of(LA, k1 >> 16); const void* sB1 = src_of(LB, k1 & 0xffff);
-        float d0 = 0.f, d1 = 0.f;
+        float d0 = 0.f, d1 = 0.f, na0 = 0.f, nb0 = 0.f, na1 = 0.f, nb1 = 0.f;
         for (int c0 = lane * VEC; c0 < a.C; c0 += 64 * VEC) {
             const Pack<T, VEC> pa0 = load_pack<T, VEC>(sA0, (int64_t)rowA0 * a.C + c0);
             const Pack<T, VEC> pb0 = load_pack<T, VEC>(sB0, (int64_t)rowB0 * a.C + c0);
@@ -161,17 +161,25 @@ __global__ void __launch_bounds__(256) k_pairs(TemporalArgs a) {
             const Pack<T, VEC> pb1 = load_pack<T, VEC>(sB1, (int64_t)rowB1 * a.C + c0);
             d0 += dot_pack(pa0, pb0);
             d1 += dot_pack(pa1, pb1);
+            if (a.inline_norms) {           // the per-head spatial kernel does not produce whole-vector norms
+                na0 += dot_pack(pa0, pa0); nb0 += dot_pack(pb0, pb0);
+                na1 += dot_pack(pa1, pa1); nb1 += dot_pack(pb1, pb1);
+            }
         }
         d0 = wave_sum(d0);
         d1 = wave_sum(d1);
+        if (a.inline_norms) { na0 = wave_sum(na0); nb0 = wave_sum(nb0); na1 = wave_sum(na1); nb1 = wave_sum(nb1); }
         if (lane < 2 && (lane == 0 || two)) {
             const int rowA = lane ? rowA1 : rowA0, rowB = lane ? rowB1 : rowB0;
             const float dot = lane ? d1 : d0;
             // x / (|x| + 1e-8) on both sides (quadtree_temporal_merger.py:62-63); the spatial kernel stored
             // 1 / (|x| + 1e-8) in double
-            const float sim = (float)((double)dot * a.inrm[rowA] * a.inrm[rowB]);
+            const double ia = a.inline_norms ? 1.0 / (sqrt((double)(lane ? na1 : na0)) + 1e-8) : a.inrm[rowA];
+            const double ib = a.inline_norms ? 1.0 / (sqrt((double)(lane ? nb1 : nb0)) + 1e-8) : a.inrm[rowB];
+            const float sim = (float)((double)dot * ia * ib);
             if (sim >= a.temporal_thresh) {
                 const int e = atomicAdd(&nkept, 1);
+                if (a.edge_sim) a.edge_sim[cidx * cap + e] = sim;
                 my_edges[e] = (int)(((unsigned)row_to_slot(a, col, rowA) << 16) | (unsigned)row_to_slot(a, col, rowB));
             }
         }
@@ -197,6 +205,91 @@ hipError_t launch_pairs(const TemporalArgs& a, hipStream_t stream) {
         if (a.vec == 8) STTM_LAUNCH_PAIRS(f16_t, 8); else if (a.vec == 4) STTM_LAUNCH_PAIRS(f16_t, 4); else STTM_LAUNCH_PAIRS(f16_t, 2);
     }
 #undef STTM_LAUNCH_PAIRS
+    return hipGetLastError();
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// slow_ver (get_cross_frame_node_pairs_slow, quadtree_temporal_merger.py:75-121): per frame pair, the kept edges of
+// ALL root cells are ordered by similarity, descending, and an edge is dropped when its src (later-frame node)
+// equals the src of the edge right before it in that order -- adjacent-duplicate removal, not an arg-max per src.
+// One workgroup per frame pair: gather -> bitonic sort in LDS -> filter -> rewrite the per-column lists.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_slow_filter(TemporalArgs a, int npad) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* key = reinterpret_cast<float*>(smem_raw);            // [npad] similarity
+    int* ent = reinterpret_cast<int*>(key + npad);               // [npad] packed local slots (dst << 16 | src)
+    int* colr = ent + npad;                                       // [npad] root cell
+    int* ccnt = colr + npad;                                      // [R] rebuilt list lengths
+    __shared__ int n_sh;
+    const int t = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int nf = a.T - 1, R = a.R, cap = a.ecap;
+    if (tid == 0) n_sh = 0;
+    for (int r = tid; r < R; r += nt) ccnt[r] = 0;
+    __syncthreads();
+    for (int j = tid; j < R * cap; j += nt) {
+        const int r = j / cap, e = j - r * cap;
+        const int64_t cidx = (int64_t)r * nf + t;
+        if (e < a.edge_cnt[cidx]) {
+            const int pos = atomicAdd(&n_sh, 1);
+            key[pos] = a.edge_sim[cidx * cap + e];
+            ent[pos] = a.edges[cidx * cap + e];
+            colr[pos] = r;
+        }
+    }
+    __syncthreads();
+    const int n = n_sh;
+    for (int i = n + tid; i < npad; i += nt) { key[i] = -INFINITY; ent[i] = -1; colr[i] = -1; }
+    __syncthreads();
+    // the gather order is nondeterministic (atomics): make the sort total by breaking similarity ties on
+    // (root cell, packed entry), so the result does not depend on arrival order
+    auto before = [&](int i, int j) {       // true if element i must come before element j (descending similarity)
+        if (key[i] != key[j]) return key[i] > key[j];
+        if (colr[i] != colr[j]) return colr[i] < colr[j];
+        return ent[i] < ent[j];
+    };
+    for (int k = 2; k <= npad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < npad; i += nt) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const bool up = (i & k) == 0;
+                    const bool swap = up ? before(l, i) : before(i, l);
+                    if (swap) {
+                        const float fk = key[i]; key[i] = key[l]; key[l] = fk;
+                        const int fe = ent[i]; ent[i] = ent[l]; ent[l] = fe;
+                        const int fc = colr[i]; colr[i] = colr[l]; colr[l] = fc;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // drop an edge whose src equals the previous edge's src (same root cell and same src slot)
+    for (int i = tid; i < n; i += nt) {
+        const bool dup = i > 0 && colr[i] == colr[i - 1] && (ent[i] & 0xffff) == (ent[i - 1] & 0xffff);
+        if (!dup) {
+            const int r = colr[i];
+            const int pos = atomicAdd(&ccnt[r], 1);
+            a.edges[((int64_t)r * nf + t) * cap + pos] = ent[i];
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < R * cap; j += nt) {
+        const int r = j / cap, e = j - r * cap;
+        if (e >= ccnt[r]) a.edges[((int64_t)r * nf + t) * cap + e] = -1;
+    }
+    for (int r = tid; r < R; r += nt) a.edge_cnt[(int64_t)r * nf + t] = ccnt[r];
+}
+
+hipError_t launch_slow_filter(const TemporalArgs& a, hipStream_t stream) {
+    if (a.T < 2) return hipSuccess;
+    int npad = 2;
+    while (npad < a.R * a.ecap) npad <<= 1;                       // worst case: every list full
+    const size_t smem = sizeof(int) * ((size_t)3 * npad + a.R);
+    if (smem > 150 * 1024) return hipErrorInvalidValue;
+    int nthreads = npad < 1024 ? (npad < 64 ? 64 : npad) : 1024;
+    hipLaunchKernelGGL(k_slow_filter, dim3(a.T - 1), dim3(nthreads), smem, stream, a, npad);
     return hipGetLastError();
 }
 

@@ -26,7 +26,7 @@ def _counts_host(device):
     return buf
 
 
-def quadtree_merge_raw(x, threshold, temporal_thresh, root_level, weighted_avg, head_dim):
+def quadtree_merge_raw(x, threshold, temporal_thresh, root_level, weighted_avg, head_dim, slow_ver=False):
     """Launch the merge of one video and return the worst-case-sized outputs plus the host counts.
     x: logical [T, C, H, W] CUDA tensor (any strides; channels-last views run zero-copy)."""
     if not x.is_cuda:
@@ -71,7 +71,7 @@ def quadtree_merge_raw(x, threshold, temporal_thresh, root_level, weighted_avg, 
         rc = lib.sttm_quadtree_merge_async(
             x.data_ptr(), x.stride(0), x.stride(1), x.stride(2), x.stride(3), T, C, H, W, dtype,
             float(threshold), float(temporal_thresh), int(root_level), int(bool(weighted_avg)), head_dim,
-            ws.data_ptr(), ws.numel(), feat.data_ptr(), npatch.data_ptr(), tlbr.data_ptr(), counts.data_ptr(),
+            int(bool(slow_ver)), ws.data_ptr(), ws.numel(), feat.data_ptr(), npatch.data_ptr(), tlbr.data_ptr(), counts.data_ptr(),
             host.data_ptr(), seq, stream.cuda_stream)
         _lib.raise_for(rc)
         # Output sizes are data dependent, so the host must learn N' -- but only N': the rank kernel publishes the
@@ -96,9 +96,7 @@ def get_quadtree_features(_video_feature, threshold, temporal_thresh=-1.0, root_
         raise NotImplementedError("vis_flag=True (quadtree_builder_vis) is a plotting aid and is out of scope")
     if pos_embs is not None:
         raise NotImplementedError("pos_embs merging (position-embedding ablation) is not implemented yet")
-    if slow_ver and temporal_thresh > 0:
-        raise NotImplementedError("slow_ver=True temporal merging is not implemented on the device path yet")
     feat, npatch, tlbr, cnt = quadtree_merge_raw(_video_feature, threshold, temporal_thresh, root_level,
-                                                 weighted_avg, head_dim)
+                                                 weighted_avg, head_dim, slow_ver)
     n = cnt[_lib.CNT_OUT]
     return feat[:n], npatch[:n], tlbr[:n]

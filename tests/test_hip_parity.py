@@ -37,11 +37,10 @@ def _check(out, exp, tol, what=""):
 
 
 def _supported(meta):
-    kw = meta["kw"]
-    return not kw.get("slow_ver")
+    return True
 
 
-GOLDEN = [p for p in case_paths(["sp_", "st_"])]
+GOLDEN = [p for p in case_paths(["sp_", "st_", "sl_"])]
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=os.path.basename)
@@ -111,6 +110,23 @@ def test_per_head_similarity_against_oracle(T, C, H, W, hd, dtype, root):
     exp = O.get_quadtree_features(x, 0.85, 0.55, root, head_dim=hd)
     out = get_quadtree_features(x.to(_dev()), 0.85, 0.55, root, head_dim=hd)
     _check(out, exp, FP32_TOL if dtype == torch.float32 else BF16_TOL, f"head_dim={hd}")
+
+
+@pytest.mark.parametrize("T,C,H,W,seed,kind", [(12, 256, 14, 14, 80, "synth"), (10, 64, 14, 14, 81, "smooth"), (6, 128, 18, 26, 82, "synth"),
+                                                 (8, 128, 27, 27, 83, "smooth")])
+def test_slow_ver_against_oracle(T, C, H, W, seed, kind):
+    from oracle import sttm_oracle as O
+    from sttm_amd import get_quadtree_features
+    from sttm_amd.synth import synth_video
+    kw = dict(c=0.15, p_static=0.7) if kind == "smooth" else {}
+    x = synth_video(T, C, H, W, seed=seed, **kw)
+    exp = O.get_quadtree_features(x, 0.85, 0.5, 1, slow_ver=True)
+    out = get_quadtree_features(x.to(_dev()), 0.85, 0.5, 1, slow_ver=True)
+    _check(out, exp, FP32_TOL, f"slow_ver {kind}")
+    # slow_ver ignores head_dim in the temporal stage but the spatial stage still honours it
+    exp = O.get_quadtree_features(x, 0.85, 0.5, 1, slow_ver=True, head_dim=32)
+    out = get_quadtree_features(x.to(_dev()), 0.85, 0.5, 1, slow_ver=True, head_dim=32)
+    _check(out, exp, FP32_TOL, f"slow_ver+head {kind}")
 
 
 def test_nchw_contiguous_input_is_accepted():

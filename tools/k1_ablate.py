@@ -22,7 +22,7 @@ for it in range(40):
     x = pool[it % 8]
     # temporal_thresh = -1: skips the pair kernel; garbage metadata from ablated modes is never dereferenced by it
     rc = lib.sttm_quadtree_merge(x.data_ptr(), x.stride(0), x.stride(1), x.stride(2), x.stride(3), T, C, H, W, 0,
-                                 0.85, -1.0, 1, 0, 0, ws.data_ptr(), nbytes, feat.data_ptr(), npatch.data_ptr(),
+                                 0.85, -1.0, 1, 0, 0, 0, ws.data_ptr(), nbytes, feat.data_ptr(), npatch.data_ptr(),
                                  tlbr.data_ptr(), counts.data_ptr(), torch.cuda.current_stream().cuda_stream)
     assert rc == 0, _lib.last_error()
     lib.sttm_profile_last(ms)

@@ -23,7 +23,7 @@ names = ["start", "gathered", "probed", "barrier1", "replayed", "counted", "offs
 acc = None
 for it in range(12):
     rc = lib.sttm_quadtree_merge(x.data_ptr(), x.stride(0), x.stride(1), x.stride(2), x.stride(3), T, C, H, W, 0,
-                                 0.85, 0.55, 1, 0, 0, ws.data_ptr(), nbytes, feat.data_ptr(), npatch.data_ptr(),
+                                 0.85, 0.55, 1, 0, 0, 0, ws.data_ptr(), nbytes, feat.data_ptr(), npatch.data_ptr(),
                                  tlbr.data_ptr(), counts.data_ptr(), torch.cuda.current_stream().cuda_stream)
     assert rc == 0
     torch.cuda.synchronize()
