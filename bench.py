@@ -122,7 +122,7 @@ def main():
     lib.sttm_profile_enable(1)
     ms = (ctypes.c_float * 4)()
     tot = [0.0] * 4
-    nodes = merged = 0
+    nodes = merged = leafnodes = 0
     calls = 0
     for s in range(K):
         for v in range(V):
@@ -132,19 +132,21 @@ def main():
             for i in range(4):
                 tot[i] += ms[i]
             nodes += cnt[_lib.CNT_NODES]
+            leafnodes += cnt[_lib.CNT_LEAFNODES]
             merged += cnt[_lib.CNT_OUT]
             calls += 1
     lib.sttm_profile_enable(0)
     log("roofline leg done: " + ", ".join(f"{k}={t / calls:.4f} ms" for k, t in zip(KERNELS, tot)))
     avg_ms = [t / calls for t in tot]
-    n_avg, m_avg = nodes / calls, merged / calls
+    n_avg, m_avg, l_avg = nodes / calls, merged / calls, leafnodes / calls
     es = 4
     thw = T * H * W
     kernel_bytes = [                                     # algorithmic (compulsory) bytes of each kernel per launch
-        es * C * thw + es * C * n_avg + 8 * thw,          # read every token once, write every node once, meta+norm
+        es * C * thw + es * C * (n_avg - l_avg) + 16 * thw,   # read every token once, write every POOLED node once (1x1
+                                                              # nodes stay in x), meta + inverse norm + node list per token
         es * C * n_avg,                                   # every node row read once (pairs share rows)
-        4 * thw * 4,                                      # label / scan arrays, once each
-        es * C * n_avg + es * C * m_avg + 24 * m_avg,     # read node rows, write merged rows + tlbr + num_patches
+        4 * thw * 6,                                      # label / group / rank tables, once each
+        es * C * n_avg + es * C * m_avg,                  # read node rows, write merged rows
     ]
     dom = max(range(4), key=lambda i: avg_ms[i])
     pipeline_bytes = es * C * thw + es * C * m_avg + 24 * m_avg      # B per video

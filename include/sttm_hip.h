@@ -53,6 +53,7 @@ extern "C" {
 #define STTM_CNT_OUT 3        /* N' : merged tokens written to the outputs                           */
 #define STTM_CNT_ITERS 4      /* label-propagation iterations                                        */
 #define STTM_CNT_OVERFLOW 5   /* != 0 : an internal list overflowed (never expected; outputs invalid)*/
+#define STTM_CNT_LEAFNODES 6  /* spatial-stage nodes that are single 1x1 tokens (their rows are never copied) */
 #define STTM_CNT_SLOTS 8
 
 int sttm_abi_version(void);

@@ -585,9 +585,10 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
         const int HW = a.H * a.W;
         for (int i = tid; i < slots; i += nt) cst<GMEM>(gcnt + i, 0);
         __syncthreads();
-        int nodes = 0;
+        int nodes = 0, leafnodes = 0;
         for (int i = tid; i < slots; i += nt) {
-            if (carea_ld<GMEM>(area_l, i)) { caadd<GMEM>(gcnt + cld<GMEM>(rep + i), 1); ++nodes; }
+            const int ar = carea_ld<GMEM>(area_l, i);
+            if (ar) { caadd<GMEM>(gcnt + cld<GMEM>(rep + i), 1); ++nodes; leafnodes += ar == 1 ? 1 : 0; }
         }
         __syncthreads();
         STTM_TICK(5);
@@ -695,8 +696,9 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
             if (lane == 0 && cand) atomicAdd(a.counts + STTM_CNT_CANDIDATES, cand);
         }
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) nodes += __shfl_xor(nodes, d, 64);
+        for (int d = 32; d >= 1; d >>= 1) { nodes += __shfl_xor(nodes, d, 64); leafnodes += __shfl_xor(leafnodes, d, 64); }
         if (lane == 0 && nodes) atomicAdd(a.counts + STTM_CNT_NODES, nodes);
+        if (lane == 0 && leafnodes) atomicAdd(a.counts + STTM_CNT_LEAFNODES, leafnodes);
         if (tid == 0) {
             if (E) atomicAdd(a.counts + STTM_CNT_EDGES, E);
             if (r == 0) a.counts[STTM_CNT_ITERS] = K;
