@@ -110,6 +110,18 @@ int sttm_quadtree_merge_async(const void* x, int64_t stride_t, int64_t stride_c,
 int sttm_wait_counts(const int32_t* counts_host, int seq, int timeout_us);
 
 /*
+ * Position-embedding ablation (pos_embs argument of get_quadtree_features; quadtree_spatial_merger.py:88-153,
+ * quadtree_temporal_merger.py:153-169): pool a side tensor `v` (logical [T, Cv, H, W], channels-last view) over the
+ * nodes and groups of the sttm_quadtree_merge call that ran LAST on this stream with this workspace (same T/H/W/
+ * root_level; C_feat / dtype_feat are that call's feature width and dtype, needed to find the buffers again).
+ * sum_mode = pos_emb_weighted_avg (sum-pool + divide by patches).  out: [T*H*W, Cv] worst case, rows [0, N') valid.
+ */
+int sttm_quadtree_apply(const void* v, int64_t stride_t, int64_t stride_c, int64_t stride_h, int64_t stride_w,
+                        int T, int Cv, int H, int W, int dtype_v, int sum_mode,
+                        int C_feat, int dtype_feat, int root_level, void* workspace, size_t workspace_bytes,
+                        const int32_t* counts, void* out, void* stream);
+
+/*
  * Per-kernel timing of sttm_quadtree_merge for the benchmark's roofline leg (not part of the reference API).
  * While enabled, every call records hipEvents on its stream around its four kernels;
  * sttm_profile_last waits for the last call and writes milliseconds for

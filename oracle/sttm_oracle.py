@@ -182,13 +182,15 @@ def _cosine(p, c, head_dim):
     return F.cosine_similarity(ph, ch, dim=-1, eps=EPS_SPATIAL).mean(dim=-1)
 
 
-def spatial_split(maps, geom, threshold, head_dim=None):
-    """Returns (features [N, C] input dtype, tlbr [N, 5] int32) sorted by (t, y1, x1)."""
+def spatial_split(maps, geom, threshold, head_dim=None, extra_maps=()):
+    """Returns (features [N, C] input dtype, tlbr [N, 5] int32) sorted by (t, y1, x1); with `extra_maps` (pyramids
+    of tensors that ride along, e.g. RoPE cos/sin, quadtree_builder.py:75-81) also their emitted rows."""
     T = maps[0].shape[0]
     h0, w0 = geom.dims[0]
     t_idx = torch.arange(T).repeat_interleave(h0 * w0)
     cell = torch.arange(h0 * w0).repeat(T)
     feats, boxes = [], []
+    extras = [[] for _ in extra_maps]
     for lvl in range(geom.n_level):
         fmap = maps[lvl]
         box_tab = geom.boxes(lvl)
@@ -197,6 +199,8 @@ def spatial_split(maps, geom, threshold, head_dim=None):
         if lvl == geom.n_level - 1:                                  # leaves are always emitted (:26-37)
             feats.append(parent)
             boxes.append(pbox)
+            for e, em in zip(extras, extra_maps):
+                e.append(em[lvl][t_idx, cell])
             break
         ids, ok = geom.child_table(lvl)
         kid = ids[cell]                                              # [n, 4]
@@ -206,6 +210,8 @@ def spatial_split(maps, geom, threshold, head_dim=None):
         stop = (sim >= threshold).all(dim=-1)                        # over all 4 slots incl. invalid (:68)
         feats.append(parent[stop])
         boxes.append(pbox[stop])
+        for e, em in zip(extras, extra_maps):
+            e.append(em[lvl][t_idx, cell][stop])
         go = (~stop)[:, None] & kid_ok
         t_idx = t_idx[:, None].expand(-1, 4)[go]
         cell = kid[go]
@@ -213,6 +219,8 @@ def spatial_split(maps, geom, threshold, head_dim=None):
     boxes = torch.cat(boxes)
     key = (boxes[:, 0].long() * geom.H + boxes[:, 1]) * geom.W + boxes[:, 2]
     order = torch.argsort(key)                                       # keys are unique
+    if extra_maps:
+        return feats[order], boxes[order], [torch.cat(e)[order] for e in extras]
     return feats[order], boxes[order]
 
 
@@ -327,6 +335,18 @@ def propagate_labels(pairs, N):
             return rep, iters
 
 
+def aggregate_extra(v, rep, npatch, weighted):
+    """Position embeddings ride along the groups (quadtree_temporal_merger.py:153-169)."""
+    N = v.shape[0]
+    rep = rep.to(torch.int32)
+    acc = torch.zeros_like(v).index_add_(0, rep, v)
+    cnt = torch.zeros(N, dtype=torch.int32).index_add_(0, rep, torch.ones(N, dtype=torch.int32))
+    pat = torch.zeros(N, dtype=torch.int32).index_add_(0, rep, npatch)
+    alive = cnt > 0
+    den = pat[alive] if weighted else cnt[alive]
+    return acc[alive] / den.unsqueeze(-1)
+
+
 def aggregate_groups(x, npatch, tlbr, rep, weighted_avg):
     """quadtree_temporal_merger.py:123-171: sums in the INPUT dtype, ascending node order; the
     survivor keeps its own box (quirk Q3)."""
@@ -369,32 +389,61 @@ def get_quadtree_features(_video_feature, threshold, temporal_thresh=-1.0, root_
     """quadtree_interface.py:5-13 -> quadtree_builder.py:85-235.
     Input logical [T, C, H, W]; returns (features [N', C] input dtype, num_patches [N'] int32,
     tlbr [N', 5] int32)."""
-    if vis_flag or pos_embs is not None:
-        raise NotImplementedError("oracle covers the non-vis, no-pos-emb path only")
+    if vis_flag:
+        raise NotImplementedError("oracle covers the non-vis path only")
     x = _video_feature.permute(0, 2, 3, 1)                          # [T, H, W, C] (a view for production input)
     T, H, W, C = x.shape
     geom = Geometry(H, W, root_level)
     mode = "sum" if weighted_avg else "avg"
     dbg = {}
+    pos = None
+    if pos_embs is not None:
+        # pos-emb pooling exists for even or both-odd levels only (quadtree_spatial_merger.py:88-153)
+        for lvl in range(1, geom.n_level):
+            h, w = geom.dims[lvl]
+            if (h % 2) != (w % 2):
+                raise RuntimeError("position-embedding pooling is undefined for mixed-parity grids "
+                                   f"({h}x{w}); the reference fails here too")
+        pmode = "sum" if pos_emb_weighted_avg else "avg"
+        pos = [p.permute(0, 2, 3, 1) for p in pos_embs]               # cos, sin as [T, H, W, Cp]
     if geom.n_level == 1:                                           # no pyramid (:146-174)
         feats = x.reshape(T * H * W, C)
         t = torch.arange(T, dtype=torch.int32).repeat_interleave(H * W)
         tlbr = torch.cat([t[:, None], geom.boxes(0).repeat(T, 1)], dim=1)
+        pos_nodes = [p.reshape(T * H * W, -1) for p in pos] if pos is not None else None
     else:
         maps = build_pyramid(x, geom, mode)
-        feats, tlbr = spatial_split(maps, geom, threshold, head_dim)
+        if pos is not None:
+            pmaps = [build_pyramid(p, geom, pmode) for p in pos]
+            feats, tlbr, pos_nodes = spatial_split(maps, geom, threshold, head_dim, extra_maps=pmaps)
+        else:
+            feats, tlbr = spatial_split(maps, geom, threshold, head_dim)
+            pos_nodes = None
     npatch = (tlbr[:, 3] - tlbr[:, 1]) * (tlbr[:, 4] - tlbr[:, 2])
     dbg["spatial_tlbr"] = tlbr
+    pos_out = None
     if temporal_thresh > 0:
+        node_patch = npatch
         res = temporal_merge(feats, tlbr, npatch, temporal_thresh, weighted_avg, head_dim, slow_ver,
-                             return_debug=return_debug)
+                             return_debug=True)
+        (feats, npatch, tlbr), d2 = res
+        dbg.update(d2)
+        if pos_nodes is not None:
+            pos_out = tuple(aggregate_extra(p, d2["rep"], node_patch, pos_emb_weighted_avg) for p in pos_nodes)
+    else:
+        if weighted_avg:
+            feats = feats / npatch.unsqueeze(1)                      # :225-226
+        if pos_nodes is not None:
+            if not pos_emb_weighted_avg:
+                # quirk Q11: `pos_embs_cos` is only assigned on the temporal or the weighted path (:228-233)
+                raise UnboundLocalError("local variable 'pos_embs_cos' referenced before assignment (the reference leaves "
+                                        "it unset when pos_embs is given with temporal_thresh <= 0 and "
+                                        "pos_emb_weighted_avg=False)")
+            pos_out = tuple(p / npatch.unsqueeze(1) for p in pos_nodes)
+    if pos_out is not None:
         if return_debug:
-            (feats, npatch, tlbr), d2 = res
-            dbg.update(d2)
-        else:
-            feats, npatch, tlbr = res
-    elif weighted_avg:
-        feats = feats / npatch.unsqueeze(1)                          # :225-226
+            return feats, npatch, tlbr, pos_out, dbg
+        return feats, npatch, tlbr, pos_out
     if return_debug:
         return feats, npatch, tlbr, dbg
     return feats, npatch, tlbr

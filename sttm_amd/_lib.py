@@ -25,6 +25,7 @@ SIGNATURES = {
     "sttm_quadtree_merge_async": (_i, [_vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _f, _i, _i, _i, _i,
                                        _vp, _sz, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "sttm_wait_counts": (_i, [_vp, _i, _i]),
+    "sttm_quadtree_apply": (_i, [_vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "sttm_profile_enable": (_i, [_i]),
     "sttm_profile_last": (_i, [ctypes.POINTER(ctypes.c_float)]),
     "sttm_merge_dst_idx": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),

@@ -198,6 +198,55 @@ int sttm_quadtree_merge(const void* x, int64_t stride_t, int64_t stride_c, int64
                                      tlbr_out, counts, nullptr, 0, stream_);
 }
 
+int sttm_quadtree_apply(const void* v, int64_t stride_t, int64_t stride_c, int64_t stride_h, int64_t stride_w,
+                        int T, int Cv, int H, int W, int dtype_v, int sum_mode,
+                        int C_feat, int dtype_feat, int root_level, void* workspace, size_t workspace_bytes,
+                        const int32_t* counts, void* out, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!v || !workspace || !counts || !out) return fail(STTM_ERR_ARG, "null pointer argument");
+    if (stride_c != 1) return fail(STTM_ERR_ARG, "channel stride must be 1 (channels-last view)");
+    if (dtype_v < 0 || dtype_v > 2 || Cv < 1) return fail(STTM_ERR_ARG, "bad dtype / channel count");
+    Plan p;
+    const int D = make_plan(T, H, W, C_feat, dtype_feat, root_level, &p);
+    if (D < 0) return D;
+    if (workspace_bytes < p.bytes) return fail(STTM_ERR_ARG, "workspace too small");
+    if ((size_t)Cv * elem_bytes(dtype_v) > (size_t)C_feat * elem_bytes(dtype_feat))
+        return fail(STTM_ERR_UNSUPPORTED, "the side tensor is wider than the feature rows the scratch was sized for");
+    for (int l = 1; l < D; ++l)
+        if ((p.dims.h[l] & 1) != (p.dims.w[l] & 1))
+            return fail(STTM_ERR_PARITY, "position-embedding pooling needs equal parities at every pooled level; level %dx%d is mixed",
+                        p.dims.h[l], p.dims.w[l]);
+    int nt = 0;
+    const int vec = pick_vec(Cv, dtype_v, v, stride_t, stride_h, stride_w, &nt);
+    if (!vec) return fail(STTM_ERR_UNSUPPORTED, "channel count / alignment of the side tensor is not supported");
+    Buffers b;
+    carve_all(p, T, C_feat, dtype_feat, reinterpret_cast<char*>(workspace), &b);
+    const bool dense = stride_w == Cv && stride_h == (int64_t)W * Cv && stride_t == (int64_t)H * W * Cv;
+    sttm::SpatialArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.x = v; sa.sT = stride_t; sa.sH = stride_h; sa.sW = stride_w;
+    sa.T = T; sa.H = H; sa.W = W; sa.C = Cv;
+    sa.dims = p.dims;
+    sa.sum_mode = sum_mode ? 1 : 0;
+    sa.leaves_in_x = dense ? 1 : 0;
+    sa.S = b.S; sa.rc_list = b.rc_list; sa.rc_stride = p.rc_stride;
+    hipError_t e;
+    if ((e = sttm::launch_node_apply(sa, dtype_v, vec, nt, stream)) != hipSuccess)
+        return fail(STTM_ERR_LAUNCH, "node-apply kernel: %s", hipGetErrorString(e));
+    sttm::TemporalArgs ta;
+    memset(&ta, 0, sizeof(ta));
+    ta.T = T; ta.H = H; ta.W = W; ta.C = Cv; ta.R = p.R;
+    ta.dtype = dtype_v; ta.vec = vec;
+    ta.weighted_avg = sum_mode ? 1 : 0;
+    ta.S = b.S; ta.xrows = dense ? v : nullptr;
+    ta.row_info = b.row_info; ta.members = b.members;
+    ta.counts = const_cast<int32_t*>(counts);
+    ta.feat_out = out;
+    if ((e = sttm::launch_group_mean(ta, stream)) != hipSuccess)
+        return fail(STTM_ERR_LAUNCH, "group-mean kernel: %s", hipGetErrorString(e));
+    return STTM_OK;
+}
+
 int sttm_wait_counts(const int32_t* counts_host, int seq, int timeout_us) {
     if (!counts_host) return fail(STTM_ERR_ARG, "null pointer");
     const volatile int32_t* flag = counts_host + STTM_CNT_SLOTS - 1;

@@ -15,4 +15,14 @@ hipError_t launch_spatial(const SpatialArgs& a, int dtype, int vec, int nt, hipS
     return hipErrorInvalidValue;
 }
 
+template <typename T>
+hipError_t launch_apply_t(const SpatialArgs& a, int vec, int nt, hipStream_t stream);
+
+hipError_t launch_node_apply(const SpatialArgs& a, int dtype, int vec, int nt, hipStream_t stream) {
+    if (dtype == STTM_F32) return launch_apply_t<float>(a, vec, nt, stream);
+    if (dtype == STTM_BF16) return launch_apply_t<bf16_t>(a, vec, nt, stream);
+    if (dtype == STTM_F16) return launch_apply_t<f16_t>(a, vec, nt, stream);
+    return hipErrorInvalidValue;
+}
+
 }  // namespace sttm

@@ -29,6 +29,7 @@ struct SpatialArgs {
     int32_t* bar;             // [2] zeroed here (grid-barrier counters of the fused label kernel)
 };
 hipError_t launch_spatial(const SpatialArgs& a, int dtype, int vec, int nt, hipStream_t stream);
+hipError_t launch_node_apply(const SpatialArgs& a, int dtype, int vec, int nt, hipStream_t stream);
 
 struct TemporalArgs {
     int T, H, W, C, R;        // R = root cells per frame

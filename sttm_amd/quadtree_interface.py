@@ -26,7 +26,7 @@ def _counts_host(device):
     return buf
 
 
-def quadtree_merge_raw(x, threshold, temporal_thresh, root_level, weighted_avg, head_dim, slow_ver=False):
+def quadtree_merge_raw(x, threshold, temporal_thresh, root_level, weighted_avg, head_dim, slow_ver=False, return_ctx=False):
     """Launch the merge of one video and return the worst-case-sized outputs plus the host counts.
     x: logical [T, C, H, W] CUDA tensor (any strides; channels-last views run zero-copy)."""
     if not x.is_cuda:
@@ -82,7 +82,26 @@ def quadtree_merge_raw(x, threshold, temporal_thresh, root_level, weighted_avg, 
     cnt = host.tolist()
     if cnt[_lib.CNT_OVERFLOW]:
         raise RuntimeError("libsttm_hip: internal list overflow (please report): counts=%s" % cnt)
+    if return_ctx:
+        return feat, npatch, tlbr, cnt, (x, ws, counts, dtype, stream)
     return feat, npatch, tlbr, cnt
+
+
+def _apply_side_tensor(v, ctx, root_level, sum_mode):
+    """Pool a side tensor (RoPE cos or sin, logical [T, Cv, H, W]) over the nodes / groups of the merge that just ran."""
+    x, ws, counts, dtype_feat, stream = ctx
+    lib = _lib.load()
+    if v.dtype not in _DTYPE_CODE:
+        raise NotImplementedError(f"dtype {v.dtype} is not supported")
+    T, Cv, H, W = v.shape
+    if v.stride(1) != 1 or (v.data_ptr() % 16) != 0:
+        v = v.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    out = torch.empty((T * H * W, Cv), dtype=v.dtype, device=v.device)
+    rc = lib.sttm_quadtree_apply(v.data_ptr(), v.stride(0), v.stride(1), v.stride(2), v.stride(3), T, Cv, H, W,
+                                 _DTYPE_CODE[v.dtype], int(bool(sum_mode)), x.shape[1], dtype_feat, int(root_level),
+                                 ws.data_ptr(), ws.numel(), counts.data_ptr(), out.data_ptr(), stream.cuda_stream)
+    _lib.raise_for(rc)
+    return out
 
 
 def get_quadtree_features(_video_feature, threshold, temporal_thresh=-1.0, root_level=0, weighted_avg=False,
@@ -94,9 +113,20 @@ def get_quadtree_features(_video_feature, threshold, temporal_thresh=-1.0, root_
     """
     if vis_flag:
         raise NotImplementedError("vis_flag=True (quadtree_builder_vis) is a plotting aid and is out of scope")
-    if pos_embs is not None:
-        raise NotImplementedError("pos_embs merging (position-embedding ablation) is not implemented yet")
-    feat, npatch, tlbr, cnt = quadtree_merge_raw(_video_feature, threshold, temporal_thresh, root_level,
-                                                 weighted_avg, head_dim, slow_ver)
+    if pos_embs is None:
+        feat, npatch, tlbr, cnt = quadtree_merge_raw(_video_feature, threshold, temporal_thresh, root_level,
+                                                     weighted_avg, head_dim, slow_ver)
+        n = cnt[_lib.CNT_OUT]
+        return feat[:n], npatch[:n], tlbr[:n]
+    # position-embedding ablation (quadtree_attn_monkey_patch_for_abl_pos.py): cos / sin ride along the same tree
+    cos, sin = pos_embs
+    if temporal_thresh <= 0 and not pos_emb_weighted_avg:
+        # quirk Q11 of the reference: `pos_embs_cos` is only assigned on the temporal or the weighted path
+        raise UnboundLocalError("local variable 'pos_embs_cos' referenced before assignment (reference behaviour for "
+                                "pos_embs with temporal_thresh <= 0 and pos_emb_weighted_avg=False)")
+    feat, npatch, tlbr, cnt, ctx = quadtree_merge_raw(_video_feature, threshold, temporal_thresh, root_level,
+                                                      weighted_avg, head_dim, slow_ver, return_ctx=True)
     n = cnt[_lib.CNT_OUT]
-    return feat[:n], npatch[:n], tlbr[:n]
+    out_cos = _apply_side_tensor(cos, ctx, root_level, pos_emb_weighted_avg)
+    out_sin = _apply_side_tensor(sin, ctx, root_level, pos_emb_weighted_avg)
+    return feat[:n], npatch[:n], tlbr[:n], (out_cos[:n], out_sin[:n])

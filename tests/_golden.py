@@ -27,6 +27,9 @@ def load_case(path):
     if meta["fn"] == "quadtree":
         case["npatch"] = torch.from_numpy(z["npatch"])
         case["tlbr"] = torch.from_numpy(z["tlbr"])
+        if "pos_cos_thwc" in z:
+            case["pos_embs"] = (_t(z["pos_cos_thwc"], dtype).permute(0, 3, 1, 2), _t(z["pos_sin_thwc"], dtype).permute(0, 3, 1, 2))
+            case["out_pos"] = (_t(z["out_cos"], dtype), _t(z["out_sin"], dtype))
     else:
         case["idx"] = torch.from_numpy(z["idx"])
     return case
@@ -48,4 +51,5 @@ def kat():
 def quadtree_kwargs(meta):
     kw = dict(meta["kw"])
     thr = kw.pop("threshold")
+    kw.pop("pos", None)            # channel count of the position embeddings stored in the fixture
     return thr, kw

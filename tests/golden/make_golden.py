@@ -103,6 +103,14 @@ q("sl_14_r1_smooth", kind="smooth", T=10, C=16, seed=21, threshold=0.80, tempora
   slow_ver=True)
 q("sl_18x26_r1", T=4, H=18, W=26, seed=22, threshold=0.85, temporal_thresh=0.60, root_level=1, slow_ver=True)
 
+# --- position-embedding merging (ablation path, quadtree_attn_monkey_patch_for_abl_pos.py) --------------------------
+q("pe_14_r1", T=5, seed=40, threshold=0.85, temporal_thresh=0.55, root_level=1, pos=16)
+q("pe_14_r1_pw", T=5, seed=41, threshold=0.85, temporal_thresh=0.55, root_level=1, pos=16, pos_emb_weighted_avg=True)
+q("pe_14_r1_sp_pw", T=4, seed=42, threshold=0.85, root_level=1, pos=16, pos_emb_weighted_avg=True)
+q("pe_27_r1_w_pw", T=3, H=27, W=27, seed=43, threshold=0.85, temporal_thresh=0.6, root_level=1, weighted_avg=True, pos=8,
+  pos_emb_weighted_avg=True)
+q("pe_14_r0_bf16", T=4, C=64, seed=44, dtype="bfloat16", threshold=0.85, temporal_thresh=0.55, root_level=0, pos=16)
+
 TOME_CASES = [
     dict(name="tome_v_030", T=3, C=32, H=14, W=14, seed=30, ratio=0.30, n_head=1),
     dict(name="tome_v_050", T=3, C=32, H=14, W=14, seed=31, ratio=0.50, n_head=1),
@@ -128,6 +136,8 @@ ERROR_CASES = [
     dict(name="err_sum_mixed_parity", fn="quadtree", T=2, C=8, H=13, W=24, kw=dict(threshold=0.85, root_level=1, weighted_avg=True)),
     dict(name="err_sum_mixed_parity_16x22", fn="quadtree", T=2, C=8, H=16, W=22, kw=dict(threshold=0.85, root_level=1, weighted_avg=True)),
     dict(name="err_root_level_oob", fn="quadtree", T=2, C=8, H=14, W=14, kw=dict(threshold=0.85, root_level=7)),
+    dict(name="err_pos_no_temporal_unweighted", fn="quadtree", T=2, C=8, H=14, W=14, pos=4, kw=dict(threshold=0.85, root_level=1)),
+    dict(name="err_pos_mixed_parity", fn="quadtree", T=2, C=8, H=13, W=24, pos=4, kw=dict(threshold=0.85, temporal_thresh=0.5, root_level=1)),
     dict(name="err_tome_frame", fn="tome", T=3, C=8, H=14, W=14, kw=dict(prune_ratio=0.5, tome_ver="frame")),
     dict(name="ret_tome_snippet", fn="tome", T=3, C=8, H=14, W=14, kw=dict(prune_ratio=0.5, tome_ver="snippet")),
     dict(name="ret_tome_unknown", fn="tome", T=3, C=8, H=14, W=14, kw=dict(prune_ratio=0.5, tome_ver="bogus")),
@@ -144,13 +154,24 @@ def main():
         x = make_input(case["kind"], case["T"], case["C"], case["H"], case["W"], case["seed"], dtype)
         kw = dict(case["kw"])
         thr = kw.pop("threshold")
-        feat, npatch, tlbr = get_quadtree_features(x, thr, **kw)
+        extra = {}
+        cp = kw.pop("pos", None)
+        if cp:
+            g = torch.Generator().manual_seed(case["seed"] + 7000)
+            ang = torch.rand(case["T"], case["H"], case["W"], cp, generator=g) * 6.2831853
+            pc, ps = torch.cos(ang).to(dtype), torch.sin(ang).to(dtype)          # [T, H, W, Cp] memory
+            kw["pos_embs"] = (pc.permute(0, 3, 1, 2), ps.permute(0, 3, 1, 2))
+            extra = dict(pos_cos_thwc=to_np(pc), pos_sin_thwc=to_np(ps))
+        out = get_quadtree_features(x, thr, **kw)
+        feat, npatch, tlbr = out[:3]
+        if cp:
+            extra.update(out_cos=to_np(out[3][0]), out_sin=to_np(out[3][1]))
         mem = x.permute(0, 2, 3, 1)
         assert mem.is_contiguous()
         np.savez_compressed(
             os.path.join(HERE, case["name"] + ".npz"),
             x_thwc=to_np(mem), feat=to_np(feat), npatch=to_np(npatch), tlbr=to_np(tlbr),
-            meta=json.dumps(dict(case, fn="quadtree")))
+            meta=json.dumps(dict(case, fn="quadtree")), **extra)
         summary[case["name"]] = dict(N=int(feat.shape[0]), tokens=int(case["T"] * case["H"] * case["W"]),
                                      sizes=sorted(set(npatch.tolist())))
         print(case["name"], summary[case["name"]])
@@ -174,6 +195,9 @@ def main():
         try:
             if case["fn"] == "quadtree":
                 kw = dict(case["kw"])
+                if case.get("pos"):
+                    pe = torch.rand(case["T"], case["H"], case["W"], case["pos"]).permute(0, 3, 1, 2)
+                    kw["pos_embs"] = (pe, pe.clone())
                 out = get_quadtree_features(x, kw.pop("threshold"), **kw)
             else:
                 out = get_tome_features(x, **case["kw"])

@@ -40,7 +40,7 @@ def _supported(meta):
     return True
 
 
-GOLDEN = [p for p in case_paths(["sp_", "st_", "sl_"])]
+GOLDEN = [p for p in case_paths(["sp_", "st_", "sl_", "pe_"])]
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=os.path.basename)
@@ -51,7 +51,16 @@ def test_golden_vectors(path):
         pytest.skip("variant not on the device path yet")
     thr, kw = quadtree_kwargs(c["meta"])
     x = c["x"].to(_dev())
-    out = get_quadtree_features(x, thr, **kw)
+    if "pos_embs" in c:
+        pe = tuple(p.to(_dev()) for p in c["pos_embs"])
+        out = get_quadtree_features(x, thr, pos_embs=pe, **kw)
+        tolp = FP32_TOL if x.dtype == torch.float32 else BF16_TOL
+        for got, exp in zip(out[3], c["out_pos"]):
+            assert got.shape == exp.shape and got.dtype == exp.dtype
+            assert float((got.cpu().float() - exp.float()).abs().max()) <= tolp
+        out = out[:3]
+    else:
+        out = get_quadtree_features(x, thr, **kw)
     if thr >= 1.0:
         # at threshold 1.0 the decision hinges on whether a vector's fp32 self-cosine
         # rounds to 1.0 or 0.99999994 in ATen's summation order -- not a reproducible property.  Only the
@@ -195,6 +204,9 @@ def test_error_behaviour_matches_reference(case):
     x = synth_video(case["T"], case["C"], case["H"], case["W"], seed=99).to(_dev())
     kw = dict(case["kw"])
     thr = kw.pop("threshold")
+    if case.get("pos"):
+        pe = torch.rand(case["T"], case["H"], case["W"], case["pos"], device=_dev()).permute(0, 3, 1, 2)
+        kw["pos_embs"] = (pe, pe.clone())
     with pytest.raises(getattr(__import__("builtins"), case["raises"])):
         get_quadtree_features(x, thr, **kw)
 

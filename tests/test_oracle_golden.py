@@ -8,11 +8,16 @@ from oracle import sttm_oracle as O
 from tests._golden import case_paths, kat, load_case, quadtree_kwargs
 
 
-@pytest.mark.parametrize("path", case_paths(["sp_", "st_", "sl_"]), ids=os.path.basename)
+@pytest.mark.parametrize("path", case_paths(["sp_", "st_", "sl_", "pe_"]), ids=os.path.basename)
 def test_quadtree_matches_reference(path):
     c = load_case(path)
     thr, kw = quadtree_kwargs(c["meta"])
-    feat, npatch, tlbr = O.get_quadtree_features(c["x"], thr, **kw)
+    if "pos_embs" in c:
+        feat, npatch, tlbr, pos = O.get_quadtree_features(c["x"], thr, pos_embs=c["pos_embs"], **kw)
+        for got, exp in zip(pos, c["out_pos"]):
+            assert got.dtype == exp.dtype and torch.equal(got.float(), exp.float())
+    else:
+        feat, npatch, tlbr = O.get_quadtree_features(c["x"], thr, **kw)
     assert tlbr.dtype == torch.int32 and npatch.dtype == torch.int32
     assert feat.dtype == c["feat"].dtype
     assert torch.equal(tlbr, c["tlbr"])
@@ -52,6 +57,9 @@ def test_error_behaviour(case):
     def run():
         if case["fn"] == "quadtree":
             kw = dict(case["kw"])
+            if case.get("pos"):
+                pe = torch.rand(case["T"], case["H"], case["W"], case["pos"]).permute(0, 3, 1, 2)
+                kw["pos_embs"] = (pe, pe.clone())
             return O.get_quadtree_features(x, kw.pop("threshold"), **kw)
         return O.get_tome_features(x, **case["kw"])
 
