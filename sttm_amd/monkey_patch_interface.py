@@ -85,6 +85,66 @@ def _qwen2_forward_with_merge(self, input_ids=None, attention_mask=None, positio
     return BaseModelOutputWithPast(last_hidden_state=hidden_states, past_key_values=past_key_values if use_cache else None)
 
 
+def _qwen2vl_forward_with_merge(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None,
+                                inputs_embeds=None, use_cache=None, **kwargs):
+    """transformers 5.x Qwen2VLTextModel.forward + the STTM / ToMe hook: 3-D mRoPE position ids are GATHERED by the
+    merged-token index (token_merging_qwen2vl_monkey_patch/quadtree_attn_monkey_patch.py:109-113); H and W come from
+    `self.image_H / self.image_W` (llava/model/qwen2vl/modeling_qwen2vl.py:1919-1920)."""
+    from transformers.cache_utils import DynamicCache
+    from transformers.masking_utils import create_causal_mask, create_sliding_window_causal_mask
+    from transformers.modeling_outputs import BaseModelOutputWithPast
+    if (input_ids is None) ^ (inputs_embeds is not None):
+        raise ValueError("You must specify exactly one of input_ids or inputs_embeds")
+    if use_cache and past_key_values is None:
+        past_key_values = DynamicCache(config=self.config)
+    if inputs_embeds is None:
+        inputs_embeds = self.embed_tokens(input_ids)
+    prefilling = _is_prefill(past_key_values)
+    if position_ids is None:
+        seen = past_key_values.get_seq_length() if past_key_values is not None else 0
+        position_ids = torch.arange(inputs_embeds.shape[1], device=inputs_embeds.device) + seen
+        position_ids = position_ids.view(1, 1, -1).expand(3, inputs_embeds.shape[0], -1)
+    elif position_ids.ndim == 2:
+        position_ids = position_ids[None, ...].expand(3, position_ids.shape[0], -1)
+    text_position_ids = None
+    if position_ids.ndim == 3 and position_ids.shape[0] == 4:
+        text_position_ids = position_ids[0]
+        position_ids = position_ids[1:]
+    if not isinstance(mask_map := attention_mask, dict):
+        mk = dict(config=self.config, inputs_embeds=inputs_embeds, attention_mask=attention_mask,
+                  past_key_values=past_key_values, position_ids=text_position_ids)
+        mask_map = {"full_attention": create_causal_mask(**mk)}
+        if getattr(self, "has_sliding_layers", False):
+            mask_map["sliding_attention"] = create_sliding_window_causal_mask(**mk)
+    hidden_states = inputs_embeds
+    position_embeddings = self.rotary_emb(hidden_states, position_ids)
+    merged = False
+    for i, layer in enumerate(self.layers):
+        if prefilling and not merged and i == self.sa_start_layer_idx and getattr(self, "image_token_length", None) is not None:
+            start, length, T = _item(self.image_token_start_index), _item(self.image_token_length), _item(self.num_frame)
+            H, W = _item(self.image_H), _item(self.image_W)
+            if self.sttm_pattern == "quadtree":
+                hidden_states, position_ids, _cache_pos, idx = patch_hooks.quadtree_merge_qwen2vl(
+                    hidden_states, position_ids, start, length, T, H, W, type(self).sttm_merge_fn,
+                    self.sa_tree_thresh, self.sa_tree_temporal_thresh, self.sa_tree_root_level, self.sa_tree_weighted_avg,
+                    slow_ver=self.sttm_slow_ver)
+            else:
+                hidden_states, position_ids, idx = patch_hooks.tome_merge(
+                    hidden_states, position_ids, start, length, T, type(self).sttm_tome_fn, self.sa_prune_ratio,
+                    self.sa_tome_ver, H=H, W=W)
+            if text_position_ids is not None:
+                text_position_ids = text_position_ids[..., :hidden_states.size(1)]
+            self.merged_token_1d_idx = idx
+            position_embeddings = self.rotary_emb(hidden_states, position_ids)
+            mask_map = {k: None for k in mask_map}          # batch-1 prefill without padding: plain causal
+            merged = True
+        hidden_states = layer(hidden_states, attention_mask=mask_map[self.config.layer_types[i]],
+                              position_embeddings=position_embeddings, position_ids=text_position_ids,
+                              past_key_values=past_key_values, use_cache=use_cache, **kwargs)
+    hidden_states = self.norm(hidden_states)
+    return BaseModelOutputWithPast(last_hidden_state=hidden_states, past_key_values=past_key_values)
+
+
 def _qwen2_model_class():
     import transformers.models.qwen2.modeling_qwen2 as m
     return m.Qwen2Model
@@ -134,8 +194,8 @@ def replace_qwen2_with_tome_attn(sa_start_layer_idx=0, sa_prune_ratio=0.50, sa_t
 
 def replace_qwen2vl_with_quadtree_attn(sa_start_layer_idx=0, sa_tree_thresh=0.90, sa_tree_temporal_thresh=-1.0,
                                        sa_tree_root_level=0, sa_tree_weighted_avg=False, sttm_slow_ver=False, **kwargs):
-    """Qwen2-VL: configuration is stored on the text-model class; the merge step itself is
-    `patch_hooks.quadtree_merge_qwen2vl` (3-D position-id gather + cache_position reset)."""
+    """Qwen2-VL text model (transformers 5.x `Qwen2VLTextModel`): same class-attribute mechanism, forward replaced by
+    `_qwen2vl_forward_with_merge` (3-D position-id gather)."""
     cls = _qwen2vl_model_class()
     if cls is None:
         return
@@ -149,7 +209,9 @@ def replace_qwen2vl_with_quadtree_attn(sa_start_layer_idx=0, sa_tree_thresh=0.90
     cls.sttm_slow_ver = sttm_slow_ver
     if not hasattr(cls, "sttm_merge_fn"):
         cls.sttm_merge_fn = staticmethod(get_quadtree_features)
-    cls.sttm_merge_hook = staticmethod(patch_hooks.quadtree_merge_qwen2vl)
+    if not hasattr(cls, "_sttm_original_forward"):
+        cls._sttm_original_forward = cls.forward
+    cls.forward = _qwen2vl_forward_with_merge
 
 
 def replace_qwen2vl_with_tome_attn(sa_start_layer_idx=0, sa_prune_ratio=0.50, sa_tome_ver="frame", **kwargs):
@@ -163,15 +225,17 @@ def replace_qwen2vl_with_tome_attn(sa_start_layer_idx=0, sa_prune_ratio=0.50, sa
     cls.sa_tome_ver = sa_tome_ver
     if not hasattr(cls, "sttm_tome_fn"):
         cls.sttm_tome_fn = staticmethod(get_tome_features)
-    cls.sttm_merge_hook = staticmethod(patch_hooks.tome_merge)
+    if not hasattr(cls, "_sttm_original_forward"):
+        cls._sttm_original_forward = cls.forward
+    cls.forward = _qwen2vl_forward_with_merge
 
 
 def restore_qwen2():
-    """Undo replace_qwen2_with_* (not in the reference; handy for tests)."""
-    cls = _qwen2_model_class()
-    if hasattr(cls, "_sttm_original_forward"):
-        cls.forward = cls._sttm_original_forward
-        del cls._sttm_original_forward
+    """Undo replace_qwen2[vl]_with_* (not in the reference; handy for tests)."""
+    for cls in (_qwen2_model_class(), _qwen2vl_model_class()):
+        if cls is not None and "_sttm_original_forward" in cls.__dict__:
+            cls.forward = cls._sttm_original_forward
+            del cls._sttm_original_forward
 
 
 def replace_qwen2_by_sparse_attn(pattern_name, **kwargs):

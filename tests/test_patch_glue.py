@@ -101,6 +101,55 @@ def test_patched_qwen2_forward_matches_manual_layers():
             del Qwen2Model.sttm_merge_fn
 
 
+def test_patched_qwen2vl_forward_matches_manual_layers():
+    """Qwen2-VL text model: 3-D mRoPE position ids are gathered by the merged-token index."""
+    pytest.importorskip("transformers")
+    try:
+        from transformers.models.qwen2_vl.configuration_qwen2_vl import Qwen2VLTextConfig
+        from transformers.models.qwen2_vl.modeling_qwen2_vl import Qwen2VLTextModel
+    except Exception:  # noqa: BLE001
+        pytest.skip("this transformers has no Qwen2VLTextModel")
+    torch.manual_seed(0)
+    C, T, H, W = 32, 3, 10, 18
+    cfg = Qwen2VLTextConfig(vocab_size=64, hidden_size=C, intermediate_size=64, num_hidden_layers=3, num_attention_heads=4,
+                            num_key_value_heads=2, max_position_embeddings=4096,
+                            rope_parameters={"rope_type": "default", "mrope_section": [1, 1, 2], "rope_theta": 10000.0})
+    cfg._attn_implementation = "sdpa"
+    model = Qwen2VLTextModel(cfg).eval()
+    hs, start, length = _prompt(T, H, W, C=C)
+    S = hs.shape[1]
+    pos = torch.stack([torch.arange(S), torch.arange(S) // 2, torch.arange(S) // 3]).unsqueeze(1)     # [3, 1, S]
+    try:
+        MPI.replace_qwen2_by_sparse_attn("quadtree", sa_start_layer_idx=1, sa_tree_thresh=0.85, sa_tree_temporal_thresh=0.6,
+                                         sa_tree_root_level=1)
+        Qwen2VLTextModel.sttm_merge_fn = staticmethod(O.get_quadtree_features)
+        model.image_token_start_index = torch.tensor(start)
+        model.image_token_length = torch.tensor(length)
+        model.num_frame = torch.tensor(T)
+        model.image_H = torch.tensor(H)
+        model.image_W = torch.tensor(W)
+        with torch.inference_mode():
+            out = model(inputs_embeds=hs, position_ids=pos, use_cache=False).last_hidden_state
+            h = hs
+            pe = model.rotary_emb(h, pos)
+            h = model.layers[0](h, attention_mask=None, position_embeddings=pe, position_ids=None)
+            h, p2, _, _ = patch_hooks.quadtree_merge_qwen2vl(h, pos, start, length, T, H, W, O.get_quadtree_features, 0.85, 0.6, 1, False)
+            pe = model.rotary_emb(h, p2)
+            for layer in model.layers[1:]:
+                h = layer(h, attention_mask=None, position_embeddings=pe, position_ids=None)
+            ref = model.norm(h)
+        assert out.shape == ref.shape and out.shape[1] < S
+        assert torch.allclose(out, ref, atol=1e-5)
+    finally:
+        MPI.restore_qwen2()
+        for cls in (Qwen2VLTextModel,):
+            if "sttm_merge_fn" in cls.__dict__:
+                del cls.sttm_merge_fn
+        from transformers.models.qwen2.modeling_qwen2 import Qwen2Model
+        if "sttm_merge_fn" in Qwen2Model.__dict__:
+            del Qwen2Model.sttm_merge_fn
+
+
 @pytest.mark.gpu
 def test_hook_on_gpu_uses_the_hip_path():
     from sttm_amd import get_quadtree_features
