@@ -89,6 +89,51 @@ template <typename T, int VEC>
 __device__ __forceinline__ Pack<T, VEC> load_pack(const void* base, int64_t elem_off) {
     return *reinterpret_cast<const Pack<T, VEC>*>(reinterpret_cast<const char*>(base) + elem_off * TypeInfo<T>::bytes);
 }
+// streaming variants (read-once / write-once data): nontemporal hint, keeps the L2 for the re-read structures
+template <typename T, int VEC>
+__device__ __forceinline__ Pack<T, VEC> load_pack_stream(const void* base, int64_t elem_off) {
+#ifdef STTM_NT_STREAM
+    const char* p = reinterpret_cast<const char*>(base) + elem_off * TypeInfo<T>::bytes;
+    Pack<T, VEC> out;
+    constexpr int bytes = TypeInfo<T>::bytes * VEC;
+    if constexpr (bytes == 16) {
+        const auto v = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((ext_vector_type(4))) unsigned*>(p));
+        __builtin_memcpy(&out, &v, 16);
+    } else if constexpr (bytes == 8) {
+        const auto v = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((ext_vector_type(2))) unsigned*>(p));
+        __builtin_memcpy(&out, &v, 8);
+    } else if constexpr (bytes == 4) {
+        const unsigned v = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(p));
+        __builtin_memcpy(&out, &v, 4);
+    } else {
+        out = *reinterpret_cast<const Pack<T, VEC>*>(p);
+    }
+    return out;
+#else
+    return load_pack<T, VEC>(base, elem_off);
+#endif
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void store_pack_stream(void* base, int64_t elem_off, const Pack<T, VEC>& p) {
+#ifdef STTM_NT_STREAM
+    char* d = reinterpret_cast<char*>(base) + elem_off * TypeInfo<T>::bytes;
+    constexpr int bytes = TypeInfo<T>::bytes * VEC;
+    if constexpr (bytes == 16) {
+        __attribute__((ext_vector_type(4))) unsigned v;
+        __builtin_memcpy(&v, &p, 16);
+        __builtin_nontemporal_store(v, reinterpret_cast<__attribute__((ext_vector_type(4))) unsigned*>(d));
+    } else if constexpr (bytes == 8) {
+        __attribute__((ext_vector_type(2))) unsigned v;
+        __builtin_memcpy(&v, &p, 8);
+        __builtin_nontemporal_store(v, reinterpret_cast<__attribute__((ext_vector_type(2))) unsigned*>(d));
+    } else {
+        *reinterpret_cast<Pack<T, VEC>*>(d) = p;
+    }
+#else
+    *reinterpret_cast<Pack<T, VEC>*>(reinterpret_cast<char*>(base) + elem_off * TypeInfo<T>::bytes) = p;
+#endif
+}
+
 template <typename T, int VEC>
 __device__ __forceinline__ void store_pack(void* base, int64_t elem_off, const Pack<T, VEC>& p) {
     *reinterpret_cast<Pack<T, VEC>*>(reinterpret_cast<char*>(base) + elem_off * TypeInfo<T>::bytes) = p;

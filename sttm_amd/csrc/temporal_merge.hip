@@ -894,7 +894,7 @@ __global__ void __launch_bounds__(256) k_group_mean(TemporalArgs a) {
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) acc.set(e, acc.get(e) / den);
             }
-            store_pack<T, VEC>(a.feat_out, (int64_t)row * a.C + c0, acc);
+            store_pack_stream<T, VEC>(a.feat_out, (int64_t)row * a.C + c0, acc);
         }
     }
 }
