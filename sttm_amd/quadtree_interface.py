@@ -104,6 +104,96 @@ def _apply_side_tensor(v, ctx, root_level, sum_mode):
     return out
 
 
+_side_streams = {}
+
+
+def get_quadtree_features_batch(videos, threshold, temporal_thresh=-1.0, root_level=0, weighted_avg=False,
+                                slow_ver=False, head_dim=None, n_streams=2):
+    """Extension (not in the reference, whose API is one video per call): merge a LIST of videos and return the list of
+    (features, num_patches, tlbr) triples -- results identical to calling get_quadtree_features on each.
+
+    Videos are independent, so consecutive videos are issued round-robin on `n_streams` side streams: the latency-bound
+    label kernel of one video (16 workgroups) overlaps the bandwidth-bound kernels of the next.  The host waits for the
+    per-video token counts only after everything has been enqueued; the caller's current stream is made to wait for the
+    side streams, so downstream ops stay stream-ordered."""
+    if not videos:
+        return []
+    lib = _lib.load()
+    dev = videos[0].device
+    if not all(v.is_cuda and v.device == dev for v in videos):
+        raise RuntimeError("sttm_amd runs on the GPU only: every video must be a CUDA (ROCm) tensor on one device; "
+                           "there is no CPU fallback")
+    head = 0 if head_dim is None else int(head_dim)
+    streams = _side_streams.setdefault((dev, n_streams), None)
+    with torch.cuda.device(dev):
+        if streams is None:
+            streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+            _side_streams[(dev, n_streams)] = streams
+        cur = torch.cuda.current_stream(dev)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        pend = []
+        hosts = _pinned_counts.get((dev, "batch"))
+        if hosts is None or hosts.shape[0] < len(videos):
+            hosts = torch.zeros((max(64, len(videos)), _lib.CNT_SLOTS), dtype=torch.int32).pin_memory()
+            _pinned_counts[(dev, "batch")] = hosts
+        for j, x in enumerate(videos):
+            if x.dim() != 4 or x.dtype not in _DTYPE_CODE:
+                raise ValueError("expected [T, C, H, W] float32 / bfloat16 / float16 tensors")
+            if x.stride(1) != 1 or (x.data_ptr() % 16) != 0:
+                x = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+            T, C, H, W = x.shape
+            dtype = _DTYPE_CODE[x.dtype]
+            key = (T, H, W, C, dtype, int(root_level))
+            nbytes = _ws_bytes_cache.get(key)
+            if nbytes is None:
+                nbytes = lib.sttm_quadtree_workspace_bytes(T, H, W, C, dtype, int(root_level))
+                if nbytes == 0:
+                    code = lib.sttm_quadtree_num_levels(H, W, int(root_level))
+                    _lib.raise_for(code if code < 0 else _lib.ERR_ARG)
+                _ws_bytes_cache[key] = nbytes
+            st = streams[j % n_streams]
+            if j < n_streams:
+                st.wait_event(ready)                       # inputs were produced on the caller's stream
+            skey = (dev, st.cuda_stream)
+            cached = _ws_cache.get(skey)
+            if cached is None or cached[0].numel() < nbytes:
+                cached = (torch.empty(nbytes, dtype=torch.uint8, device=dev),
+                          torch.empty(_lib.CNT_SLOTS, dtype=torch.int32, device=dev))
+                _ws_cache[skey] = cached
+            ws, counts = cached
+            N = T * H * W
+            feat = torch.empty((N, C), dtype=x.dtype, device=dev)
+            npatch = torch.empty(N, dtype=torch.int32, device=dev)
+            tlbr = torch.empty((N, 5), dtype=torch.int32, device=dev)
+            for t_ in (feat, npatch, tlbr):
+                t_.record_stream(st)
+            _seq[0] = (_seq[0] % 0x3fffffff) + 1
+            seq = _seq[0]
+            rc = lib.sttm_quadtree_merge_async(
+                x.data_ptr(), x.stride(0), x.stride(1), x.stride(2), x.stride(3), T, C, H, W, dtype,
+                float(threshold), float(temporal_thresh), int(root_level), int(bool(weighted_avg)), head, int(bool(slow_ver)),
+                ws.data_ptr(), ws.numel(), feat.data_ptr(), npatch.data_ptr(), tlbr.data_ptr(), counts.data_ptr(),
+                hosts[j].data_ptr(), seq, st.cuda_stream)
+            _lib.raise_for(rc)
+            pend.append((feat, npatch, tlbr, seq, st, counts))
+        out = []
+        for j, (feat, npatch, tlbr, seq, st, counts) in enumerate(pend):
+            if lib.sttm_wait_counts(hosts[j].data_ptr(), seq, 2_000_000) != 0:
+                st.synchronize()
+                raise RuntimeError("libsttm_hip: the token counts of a batched merge did not arrive")
+            cnt = hosts[j].tolist()
+            if cnt[_lib.CNT_OVERFLOW]:
+                raise RuntimeError("libsttm_hip: internal list overflow (please report): counts=%s" % cnt)
+            n = cnt[_lib.CNT_OUT]
+            out.append((feat[:n], npatch[:n], tlbr[:n]))
+        for st in streams:
+            done = torch.cuda.Event()
+            done.record(st)
+            cur.wait_event(done)
+    return out
+
+
 def get_quadtree_features(_video_feature, threshold, temporal_thresh=-1.0, root_level=0, weighted_avg=False,
                           vis_flag=False, slow_ver=False, head_dim=None, pos_embs=None, pos_emb_weighted_avg=False):
     """Drop-in for the reference's get_quadtree_features.

@@ -138,6 +138,20 @@ def test_slow_ver_against_oracle(T, C, H, W, seed, kind):
     _check(out, exp, FP32_TOL, f"slow_ver+head {kind}")
 
 
+def test_batched_extension_equals_per_video_calls():
+    """get_quadtree_features_batch (two side streams) returns exactly what per-video calls return."""
+    from sttm_amd import get_quadtree_features, get_quadtree_features_batch
+    from sttm_amd.synth import synth_video
+    vids = [synth_video(T, 1024, 14, 14, seed=90 + i).to(_dev()) for i, T in enumerate([16, 8, 16, 12, 16, 16, 4])]
+    single = [get_quadtree_features(v, 0.85, 0.55, 1) for v in vids]
+    for rep in range(3):
+        batch = get_quadtree_features_batch(vids, 0.85, 0.55, 1)
+        torch.cuda.synchronize()
+        assert len(batch) == len(single)
+        for (f, n, t), (ef, en, et) in zip(batch, single):
+            assert torch.equal(t, et) and torch.equal(n, en) and torch.equal(f, ef)
+
+
 def test_nchw_contiguous_input_is_accepted():
     """Not the production layout: the wrapper makes one channels-last copy and results are unchanged."""
     from oracle import sttm_oracle as O
