@@ -139,7 +139,7 @@ def main():
     from sttm_amd.quadtree_interface import get_quadtree_features_batch
     def run_step_batched(s):
         vids = [pool[(s * V + v) % P] for v in range(V)]
-        return get_quadtree_features_batch(vids, thr, tthr, root)
+        return get_quadtree_features_batch(vids, thr, tthr, root, n_streams=int(os.environ.get("STTM_BATCH_STREAMS", "3")))
     run_step_batched(0)
     torch.cuda.synchronize()
     barrier()
@@ -187,7 +187,9 @@ def main():
         4 * thw * 6,                                      # label / group / rank tables, once each
         es * C * n_avg + es * C * m_avg,                  # read node rows, write merged rows
     ]
-    dom = max(range(4), key=lambda i: avg_ms[i])
+    # the roofline is quoted for the dominant HBM-bound kernel; the label kernel (index 2) moves < 1 % of the bytes and is
+    # latency-bound by construction (16 workgroups), it is reported in kernel_ms but never as the roofline kernel
+    dom = max((0, 1, 3), key=lambda i: avg_ms[i])
     pipeline_bytes = es * C * thw + es * C * m_avg + 24 * m_avg      # B per video
     dom_gbs = kernel_bytes[dom] / (avg_ms[dom] * 1e-3) / 1e9
     pipe_gbs = pipeline_bytes / (sum(avg_ms) * 1e-3) / 1e9
@@ -261,7 +263,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "batched_extension": {"value": round(batched_value, 2), "unit": "videos/s",
-                                  "api": "get_quadtree_features_batch: the step's videos in one call, 2 side streams "
+                                  "api": "get_quadtree_features_batch: the step's videos in one call, 3 side streams "
                                          "(not the reference's batch-1 API; identical outputs)"},
         }
         if cpu:

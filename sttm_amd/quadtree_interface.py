@@ -108,7 +108,7 @@ _side_streams = {}
 
 
 def get_quadtree_features_batch(videos, threshold, temporal_thresh=-1.0, root_level=0, weighted_avg=False,
-                                slow_ver=False, head_dim=None, n_streams=2):
+                                slow_ver=False, head_dim=None, n_streams=3):
     """Extension (not in the reference, whose API is one video per call): merge a LIST of videos and return the list of
     (features, num_patches, tlbr) triples -- results identical to calling get_quadtree_features on each.
 
