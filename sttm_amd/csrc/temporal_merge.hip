@@ -153,6 +153,12 @@ __global__ void __launch_bounds__(256) k_pairs(TemporalArgs a) {
         const int rowA1 = row_of(LA, k1 >> 16, t), rowB1 = row_of(LB, k1 & 0xffff, t + 1);
         const void* sA0 = src_of(LA, k0 >> 16); const void* sB0 = src_of(LB, k0 & 0xffff);
         const void* sA1 = src_of(LA, k1 >> 16); const void* sB1 = src_of(LB, k1 & 0xffff);
+        // the two lanes that finish the cosines fetch their inverse norms now, under the row loads
+        double pre_ia = 0.0, pre_ib = 0.0;
+        if (lane < 2 && !a.inline_norms) {
+            pre_ia = a.inrm[lane ? rowA1 : rowA0];
+            pre_ib = a.inrm[lane ? rowB1 : rowB0];
+        }
         float d0 = 0.f, d1 = 0.f, na0 = 0.f, nb0 = 0.f, na1 = 0.f, nb1 = 0.f;
         for (int c0 = lane * VEC; c0 < a.C; c0 += 64 * VEC) {
             const Pack<T, VEC> pa0 = load_pack<T, VEC>(sA0, (int64_t)rowA0 * a.C + c0);
@@ -174,8 +180,8 @@ __global__ void __launch_bounds__(256) k_pairs(TemporalArgs a) {
             const float dot = lane ? d1 : d0;
             // x / (|x| + 1e-8) on both sides (quadtree_temporal_merger.py:62-63); the spatial kernel stored
             // 1 / (|x| + 1e-8) in double
-            const double ia = a.inline_norms ? 1.0 / (sqrt((double)(lane ? na1 : na0)) + 1e-8) : a.inrm[rowA];
-            const double ib = a.inline_norms ? 1.0 / (sqrt((double)(lane ? nb1 : nb0)) + 1e-8) : a.inrm[rowB];
+            const double ia = a.inline_norms ? 1.0 / (sqrt((double)(lane ? na1 : na0)) + 1e-8) : pre_ia;
+            const double ib = a.inline_norms ? 1.0 / (sqrt((double)(lane ? nb1 : nb0)) + 1e-8) : pre_ib;
             const float sim = (float)((double)dot * ia * ib);
             if (sim >= a.temporal_thresh) {
                 const int e = atomicAdd(&nkept, 1);
