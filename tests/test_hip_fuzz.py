@@ -1,0 +1,60 @@
+"""Seeded fuzz of the HIP path against the oracle over random shapes / thresholds / variants (small sizes)."""
+import random
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases(n, seed):
+    rng = random.Random(seed)
+    out = []
+    while len(out) < n:
+        H, W = rng.randint(3, 30), rng.randint(3, 40)
+        T = rng.randint(1, 7)
+        C = rng.choice([8, 12, 16, 20, 32, 64, 100, 128, 256])
+        dtype = rng.choice([torch.float32, torch.float32, torch.bfloat16, torch.float16])
+        if dtype != torch.float32 and C % 2:
+            continue
+        root = rng.choice([-2, -1, 0, 1, 1, 1, 2])
+        thr = rng.choice([0.6, 0.75, 0.8, 0.85, 0.9, 0.95])
+        tthr = rng.choice([-1.0, 0.3, 0.5, 0.55, 0.7])
+        weighted = rng.random() < 0.25
+        slow = rng.random() < 0.2 and tthr > 0
+        kind = rng.choice(["synth", "smooth", "iid"])
+        out.append((T, C, H, W, dtype, root, thr, tthr, weighted, slow, kind, rng.randint(0, 10 ** 6)))
+    return out
+
+
+@pytest.mark.parametrize("case", _cases(200, 1234), ids=lambda c: "T%d_C%d_%dx%d_r%d_%s" % (c[0], c[1], c[2], c[3], c[5], c[10]))
+def test_fuzz_against_oracle(case):
+    from oracle import sttm_oracle as O
+    from sttm_amd import get_quadtree_features
+    from sttm_amd.synth import iid_video, synth_video
+    T, C, H, W, dtype, root, thr, tthr, weighted, slow, kind, seed = case
+    if kind == "iid":
+        x = iid_video(T, C, H, W, seed=seed, dtype=dtype)
+    else:
+        kw = dict(c=0.15, p_static=0.7) if kind == "smooth" else {}
+        x = synth_video(T, C, H, W, seed=seed, dtype=dtype, **kw)
+    dev = torch.device("cuda:0")
+    try:
+        exp = O.get_quadtree_features(x, thr, tthr, root, weighted, slow_ver=slow)
+    except (IndexError, RuntimeError) as e:      # out-of-range root level / sum-pool on mixed parity: same error type here
+        with pytest.raises(type(e)):
+            get_quadtree_features(x.to(dev), thr, tthr, root, weighted, slow_ver=slow)
+        return
+    try:
+        out = get_quadtree_features(x.to(dev), thr, tthr, root, weighted, slow_ver=slow)
+    except NotImplementedError as e:             # documented device limits (tree deeper than 5 levels, ...)
+        pytest.skip(str(e))
+    f, n, t = (o.cpu() for o in out)
+    ef, en, et = exp
+    assert t.shape == et.shape and torch.equal(t, et), f"tlbr differs: {t.shape} vs {et.shape}"
+    assert torch.equal(n, en)
+    err = (f.float() - ef.float()).abs()
+    if dtype == torch.float32:
+        assert float(err.max()) <= 1e-5
+    else:
+        assert float((err / ef.float().abs().clamp_min(1.0)).max()) <= 2 ** -7
