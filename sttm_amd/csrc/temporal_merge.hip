@@ -19,6 +19,8 @@
 // connected components), so the columns must all run the same number of iterations: the PROBE pass reports
 // each column's per-iteration idempotency, the FINAL pass derives the global count K from all reports and
 // replays exactly K iterations.  No grid barrier, no co-residency assumption, no same-address atomics.
+#include <cstdlib>
+
 #include "sttm_kernels.h"
 
 namespace sttm {
@@ -908,7 +910,9 @@ __global__ void __launch_bounds__(256) k_group_mean(TemporalArgs a) {
 hipError_t launch_group_mean(const TemporalArgs& a, hipStream_t stream) {
     const int N = a.T * a.H * a.W;
     int grid = (N + 3) / 4;
-    if (grid > 4096) grid = 4096;
+    static int cap = -1;
+    if (cap < 0) { const char* e = getenv("STTM_GM_GRID"); cap = e ? atoi(e) : 4096; }
+    if (grid > cap) grid = cap;
     if (grid < 1) grid = 1;
 #define STTM_LAUNCH_GM(TT, VV) hipLaunchKernelGGL((k_group_mean<TT, VV>), dim3(grid), dim3(256), 0, stream, a)
     if (a.dtype == STTM_F32) {
