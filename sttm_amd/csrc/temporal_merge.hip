@@ -39,6 +39,7 @@ __device__ __forceinline__ void st_agent(int32_t* p, int v) {
 // ---------------------------------------------------------------------------------------------------
 struct Column {
     int Y1, X1, ah, aw, A, slots, base;   // base = T * (leaves of the root cells before this one)
+    unsigned mA, maw;                     // ceil(2^32 / A), ceil(2^32 / aw): exact n / d for n * d < 2^32 (slots <= 65536)
 };
 __device__ __forceinline__ void root_extent(const LevelDims& g, int I, int J, int& y1, int& y2, int& x1, int& x2) {
     int lo_i = I, hi_i = I, lo_j = J, hi_j = J;
@@ -59,11 +60,13 @@ __device__ __forceinline__ Column make_column(const TemporalArgs& a, int r) {
     c.Y1 = y1; c.X1 = x1; c.ah = y2 - y1; c.aw = x2 - x1; c.A = c.ah * c.aw; c.slots = a.T * c.A;
     // leaves owned by root cells 0..r-1: full root rows above + cells to the left in this root row
     c.base = a.T * (y1 * a.W + (y2 - y1) * x1);
+    c.mA = (unsigned)((0x100000000ull + (unsigned)c.A - 1) / (unsigned)c.A);
+    c.maw = (unsigned)((0x100000000ull + (unsigned)c.aw - 1) / (unsigned)c.aw);
     return c;
 }
 __device__ __forceinline__ int slot_to_row(const TemporalArgs& a, const Column& c, int s) {
-    const int t = s / c.A, q = s - t * c.A;
-    const int ly = q / c.aw, lx = q - ly * c.aw;
+    const int t = c.A == 1 ? s : (int)__umulhi((unsigned)s, c.mA), q = s - t * c.A;
+    const int ly = c.aw == 1 ? q : (int)__umulhi((unsigned)q, c.maw), lx = q - ly * c.aw;
     return t * a.H * a.W + (c.Y1 + ly) * a.W + (c.X1 + lx);
 }
 __device__ __forceinline__ int row_to_slot(const TemporalArgs& a, const Column& c, int row) {
@@ -645,53 +648,26 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
         }
         __syncthreads();
         int32_t* out = a.members + col.base;
-        // small groups (the common case): one thread ranks its own group; big ones are left to whole waves
-        constexpr int kSmall = 24;
-        if (tid == 0) flags[0] = 0;
-        __syncthreads();
+        // node-parallel ordering: every node ranks itself inside its group's (unordered) list -- O(group size) per node,
+        // balanced over the threads -- and publishes its origin row at that rank; the representative totals the patches
         for (int i = tid; i < slots; i += nt) {
-            const int n = cld<GMEM>(gcnt + i);
-            if (n == 0) continue;
-            const int o = cld<GMEM>(aux + i) - n;          // the cursor ended at offset + n
-            const int self_row = slot_to_row(a, col, i);
-            if (n == 1) {
-                const int ar = carea_ld<GMEM>(area_l, i);
-                st_agent(out + o, self_row | (ar == 1 ? kLeafBit : 0));
-                st_agent(a.grp_np + self_row, ar);
-                continue;
-            }
-            if (n > kSmall) { flags[0] = 1; continue; }
-            int patches = 0;
-            for (int m = 0; m < n; ++m) {
-                const int v = cld<GMEM>(mem + o + m);
-                int rk = 0;
-                for (int j = 0; j < n; ++j) rk += cld<GMEM>(mem + o + j) < v ? 1 : 0;
-                const int vr = slot_to_row(a, col, v);
-                const int ar = carea_ld<GMEM>(area_l, v);
-                patches += ar;
-                st_agent(out + o + rk, vr | (ar == 1 ? kLeafBit : 0));
-            }
-            st_agent(a.grp_np + self_row, patches);
-        }
-        __syncthreads();
-        if (flags[0]) {
-            for (int i = wave; i < slots; i += nwave) {
-                const int n = cld<GMEM>(gcnt + i);
-                if (n <= kSmall) continue;
-                const int o = cld<GMEM>(aux + i) - n;
-                int patches = 0;
-                for (int m = lane; m < n; m += 64) {
-                    const int v = cld<GMEM>(mem + o + m);
-                    int rk = 0;
-                    for (int j = 0; j < n; ++j) rk += cld<GMEM>(mem + o + j) < v ? 1 : 0;
-                    const int vr = slot_to_row(a, col, v);
-                    const int ar = carea_ld<GMEM>(area_l, v);
-                    patches += ar;
-                    st_agent(out + o + rk, vr | (ar == 1 ? kLeafBit : 0));
+            const int ar = carea_ld<GMEM>(area_l, i);
+            if (!ar) continue;
+            const int r = cld<GMEM>(rep + i);
+            const int n = cld<GMEM>(gcnt + r);
+            const int o = cld<GMEM>(aux + r) - n;          // the fill cursor ended at offset + n
+            int rk = 0;
+            if (n > 1)
+                for (int j = 0; j < n; ++j) rk += cld<GMEM>(mem + o + j) < i ? 1 : 0;
+            const int row = slot_to_row(a, col, i);
+            st_agent(out + o + rk, row | (ar == 1 ? kLeafBit : 0));
+            if (r == i) {
+                int patches = ar;
+                if (n > 1) {
+                    patches = 0;
+                    for (int j = 0; j < n; ++j) patches += carea_ld<GMEM>(area_l, cld<GMEM>(mem + o + j));
                 }
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) patches += __shfl_xor(patches, d, 64);
-                if (lane == 0) st_agent(a.grp_np + slot_to_row(a, col, i), patches);
+                st_agent(a.grp_np + row, patches);
             }
         }
         STTM_TICK(8);
