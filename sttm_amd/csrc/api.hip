@@ -148,9 +148,14 @@ int make_plan(int T, int H, int W, int C, int dtype, int root_level, Plan* p) {
 
 int pick_vec(int C, int dtype, const void* x, int64_t sT, int64_t sH, int64_t sW, int* nt) {
     const int eb = elem_bytes(dtype);
-    // 16-bit inputs: 4-wide packs (8 B/lane, still full-line coalescing) keep the spatial kernel spill-free;
-    // 8-wide packs only when the row would not fit one workgroup otherwise (C > 4096)
-    const int cands_f32[] = {4, 2, 1}, cands_16[] = {4, 8, 2};
+    // 16 bytes per lane for every dtype.  For 16-bit inputs the 8-wide pack became affordable (128 VGPRs) once the
+    // dot products moved to v_dot2c_f32_bf16/f16; measured on T=128, C=3584 bf16: spatial 107 -> 84 us,
+    // group mean 69 -> 51 us, pairs 42 -> 31 us versus 4-wide packs (STTM_VEC16=4 restores them).
+    int cands_f32[] = {4, 2, 1}, cands_16[] = {8, 4, 2};
+    {
+        const char* pv = getenv("STTM_VEC16");
+        if (pv && atoi(pv) == 4) { cands_16[0] = 4; cands_16[1] = 8; }
+    }
     const int* cands = dtype == STTM_F32 ? cands_f32 : cands_16;
     for (int k = 0; k < 3; ++k) {
         const int v = cands[k];

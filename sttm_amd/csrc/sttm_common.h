@@ -147,6 +147,27 @@ __device__ __forceinline__ float dot_pack(const Pack<T, VEC>& a, const Pack<T, V
     return s;
 }
 
+// 16-bit inputs: packed dot-product instructions (v_dot2c_f32_bf16 / v_dot2c_f32_f16): two exact products added into an
+// fp32 accumulator per instruction, no unpacking.  Half the multiply-adds of the fp32 path and none of its conversions.
+typedef __bf16 sttm_bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 sttm_f16x2 __attribute__((ext_vector_type(2)));
+template <int VEC>
+__device__ __forceinline__ float dot_pack(const Pack<bf16_t, VEC>& a, const Pack<bf16_t, VEC>& b) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC / 2; ++i)
+        s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(sttm_bf16x2, a.w[i]), __builtin_bit_cast(sttm_bf16x2, b.w[i]), s, false);
+    return s;
+}
+template <int VEC>
+__device__ __forceinline__ float dot_pack(const Pack<f16_t, VEC>& a, const Pack<f16_t, VEC>& b) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC / 2; ++i)
+        s = __builtin_amdgcn_fdot2(__builtin_bit_cast(sttm_f16x2, a.w[i]), __builtin_bit_cast(sttm_f16x2, b.w[i]), s, false);
+    return s;
+}
+
 // ---- wave-level reductions -----------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
