@@ -209,7 +209,7 @@ hipError_t launch_pairs(const TemporalArgs& a, hipStream_t stream) {
     const size_t smem = sizeof(int) * (size_t)a.ecap;
 #define STTM_LAUNCH_PAIRS(TT, VV) hipLaunchKernelGGL((k_pairs<TT, VV>), dim3(grid), dim3(256), smem, stream, a)
     if (a.dtype == STTM_F32) {
-        if (a.vec == 4) STTM_LAUNCH_PAIRS(float, 4); else if (a.vec == 2) STTM_LAUNCH_PAIRS(float, 2); else STTM_LAUNCH_PAIRS(float, 1);
+        if (a.vec == 8) STTM_LAUNCH_PAIRS(float, 8); else if (a.vec == 4) STTM_LAUNCH_PAIRS(float, 4); else if (a.vec == 2) STTM_LAUNCH_PAIRS(float, 2); else STTM_LAUNCH_PAIRS(float, 1);
     } else if (a.dtype == STTM_BF16) {
         if (a.vec == 8) STTM_LAUNCH_PAIRS(bf16_t, 8); else if (a.vec == 4) STTM_LAUNCH_PAIRS(bf16_t, 4); else STTM_LAUNCH_PAIRS(bf16_t, 2);
     } else {
@@ -892,7 +892,7 @@ hipError_t launch_group_mean(const TemporalArgs& a, hipStream_t stream) {
     if (grid < 1) grid = 1;
 #define STTM_LAUNCH_GM(TT, VV) hipLaunchKernelGGL((k_group_mean<TT, VV>), dim3(grid), dim3(256), 0, stream, a)
     if (a.dtype == STTM_F32) {
-        if (a.vec == 4) STTM_LAUNCH_GM(float, 4); else if (a.vec == 2) STTM_LAUNCH_GM(float, 2); else STTM_LAUNCH_GM(float, 1);
+        if (a.vec == 8) STTM_LAUNCH_GM(float, 8); else if (a.vec == 4) STTM_LAUNCH_GM(float, 4); else if (a.vec == 2) STTM_LAUNCH_GM(float, 2); else STTM_LAUNCH_GM(float, 1);
     } else if (a.dtype == STTM_BF16) {
         if (a.vec == 8) STTM_LAUNCH_GM(bf16_t, 8); else if (a.vec == 4) STTM_LAUNCH_GM(bf16_t, 4); else STTM_LAUNCH_GM(bf16_t, 2);
     } else {
