@@ -1,24 +1,24 @@
 // K2..K5 -- temporal stage of STTM on gfx950.
 //
 //   k_pairs        candidate pairs + cosine filter            (quadtree_temporal_merger.py:8-73 of the reference)
-//   k_col_labels   label propagation per root-cell column, in LDS                              (:223-269)
-//                  <PROBE>: records after which iterations the column is idempotent
-//                  <FINAL>: replays exactly the global iteration count, then builds survivors + group lists
-//   k_rank         output row of every survivor (prefix sum in origin order)      (bookkeeping of :134-140)
-//   k_group_mean   per-survivor ascending-order accumulation and mean                           (:123-171)
+//   k_slow_filter  slow_ver: per frame pair, similarity sort + adjacent-duplicate removal                (:75-121)
+//   k_col_labels   label propagation per root-cell column, in LDS                                      (:223-269)
+//                  <FUSED>: probe -> grid barrier -> exact replay -> groups -> grid barrier -> ranks, one launch
+//                  <PROBE> / <FINAL> + k_rank: the same code as three launches when co-residency is not guaranteed
+//   k_group_mean   per-survivor ascending-order accumulation and mean                                   (:123-171)
 //
 // All of them address nodes by their ORIGIN ROW  t*H*W + y1*W + x1  in the scratch matrix S written by the
-// spatial kernel.  Origin rows are ordered exactly like the reference's sorted node indices, so min-label
-// propagation over origin rows is the same computation as over node indices.
+// spatial kernel (1x1 nodes stay in x).  Origin rows are ordered exactly like the reference's sorted node
+// indices, so min-label propagation over origin rows is the same computation as over node indices.
 //
 // Structure that makes this cheap: a node lies inside exactly one root cell and root cells are the same in
 // every frame, so (a) candidate pairs never cross root cells -- one workgroup per (frame pair, root cell)
 // enumerates <= 16x16 box tests instead of the reference's dense [T-1, M, M, 4] tensor -- and (b) the label
 // graph splits into R independent columns (one per root cell, T frames deep) that fit in LDS.  The reference's
 // loop is synchronous and stops at the first iteration where ALL labels are idempotent (quirk Q2: that is not
-// connected components), so the columns must all run the same number of iterations: the PROBE pass reports
-// each column's per-iteration idempotency, the FINAL pass derives the global count K from all reports and
-// replays exactly K iterations.  No grid barrier, no co-residency assumption, no same-address atomics.
+// connected components), so the columns must all run the same number of iterations: every column probes to its
+// fixed point and records after which iterations it was idempotent; the global count K is the first iteration
+// at which all columns were; a column whose fixed point came later replays exactly K iterations.
 #include <cstdlib>
 
 #include "sttm_kernels.h"
@@ -750,7 +750,7 @@ hipError_t launch_labels_fused(const TemporalArgs& a, hipStream_t stream) {
 
 // ---------------------------------------------------------------------------------------------------
 // K4: rank.  One workgroup per frame: rows of frames before it (sum of frame_cnt) + a scan of its own
-// H*W origin slots.  row2origin[rank] = origin row of the survivor.
+// H*W origin slots; writes row_info, tlbr and num_patches of every output row.
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_rank(TemporalArgs a) {
     __shared__ int wsum[16];
