@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace sttm {
 
 constexpr int kMaxLevels = 5;   // deepest pyramid the fused spatial kernel supports (root .. leaf)
@@ -145,6 +147,19 @@ __device__ __forceinline__ float dot_pack(const Pack<T, VEC>& a, const Pack<T, V
 #pragma unroll
     for (int i = 0; i < VEC; ++i) s = fmaf(a.get(i), b.get(i), s);
     return s;
+}
+// fp32, even widths: two independent fma chains on a float2 (v_pk_fma_f32: two fmas per VALU issue), joined at the end
+typedef float sttm_f32x2 __attribute__((ext_vector_type(2)));
+template <int VEC>
+__device__ __forceinline__ typename std::enable_if<(VEC % 2 == 0), float>::type
+dot_pack(const Pack<float, VEC>& a, const Pack<float, VEC>& b) {
+    sttm_f32x2 acc = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < VEC; i += 2) {
+        const sttm_f32x2 x = {a.v[i], a.v[i + 1]}, y = {b.v[i], b.v[i + 1]};
+        acc = __builtin_elementwise_fma(x, y, acc);
+    }
+    return acc.x + acc.y;
 }
 
 // 16-bit inputs: packed dot-product instructions (v_dot2c_f32_bf16 / v_dot2c_f32_f16): two exact products added into an
