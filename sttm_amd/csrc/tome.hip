@@ -21,12 +21,12 @@ namespace sttm {
 // normalise: m = mean over heads of x.reshape(n, n_head, D); m /= |m| ; a = m[0::2], b = m[1::2]
 // one wave per token row
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_tome_normalize(const float* __restrict__ x, int n, int C, int n_head, int D,
+__global__ void __launch_bounds__(256) k_tome_normalize(const float* __restrict__ x, int n, int C, int n_head, int D, int Dp,
                                                         float* __restrict__ ahat, float* __restrict__ bhat) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     for (int row = blockIdx.x * nwave + wave; row < n; row += gridDim.x * nwave) {
         const float* xr = x + (int64_t)row * C;
-        float* out = ((row & 1) ? bhat : ahat) + (int64_t)(row >> 1) * D;
+        float* out = ((row & 1) ? bhat : ahat) + (int64_t)(row >> 1) * Dp;   // rows padded with zeros to the k-tile
         float ss = 0.f;
         for (int d = lane; d < D; d += 64) {
             float m;
@@ -43,6 +43,7 @@ __global__ void __launch_bounds__(256) k_tome_normalize(const float* __restrict_
         ss = wave_sum(ss);
         const float nrm = sqrtf(ss);
         for (int d = lane; d < D; d += 64) out[d] = out[d] / nrm;
+        for (int d = D + lane; d < Dp; d += 64) out[d] = 0.f;
     }
 }
 
@@ -82,6 +83,21 @@ __global__ void __launch_bounds__(256, 2) k_tome_match(const float* __restrict__
     int bestj[2] = {0x7fffffff, 0x7fffffff};
     const int lcol = lane & 31, lhalf = lane >> 5;
 
+    // Software pipeline: the global loads of k-tile n+1 are issued right after tile n has been written to LDS, so their
+    // latency is covered by the 64 MFMAs of tile n instead of stalling the workgroup at the top of every k step.
+    float4 ra[4], rb[4];
+    // rows are padded to a multiple of TM_K (zeros) by k_tome_normalize, so a stage never needs a k bound; rows past
+    // the end are clamped to the last row: their scores are computed and then ignored (j < nb / i < na below)
+    auto fetch = [&](int j0, int k0) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int ri = min(i0 + p * 32 + srow, na - 1), rj = min(j0 + p * 32 + srow, nb - 1);
+            ra[p] = *reinterpret_cast<const float4*>(ahat + (int64_t)ri * D + k0 + skq);
+            rb[p] = *reinterpret_cast<const float4*>(bhat + (int64_t)rj * D + k0 + skq);
+        }
+    };
+    if (jt_lo < jt_hi) fetch(jt_lo * TM_J, 0);
+
     for (int jt = jt_lo; jt < jt_hi; ++jt) {
         const int j0 = jt * TM_J;
         f32x16 acc[2][2];     // [j-subtile][i-subtile]
@@ -93,20 +109,8 @@ __global__ void __launch_bounds__(256, 2) k_tome_match(const float* __restrict__
                 for (int e = 0; e < 16; ++e) acc[p][q][e] = 0.f;
 
         for (int k0 = 0; k0 < D; k0 += TM_K) {
-            // stage: global (row-major, k contiguous) -> registers -> LDS transposed [k][row]
-            float4 ra[4], rb[4];
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int ri = i0 + p * 32 + srow, rj = j0 + p * 32 + srow;
-                const int kk = k0 + skq;
-                ra[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-                rb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ri < na && kk + 3 < D) ra[p] = *reinterpret_cast<const float4*>(ahat + (int64_t)ri * D + kk);
-                else if (ri < na) { float t[4] = {0, 0, 0, 0}; for (int c = 0; c < 4; ++c) if (kk + c < D) t[c] = ahat[(int64_t)ri * D + kk + c]; ra[p] = make_float4(t[0], t[1], t[2], t[3]); }
-                if (rj < nb && kk + 3 < D) rb[p] = *reinterpret_cast<const float4*>(bhat + (int64_t)rj * D + kk);
-                else if (rj < nb) { float t[4] = {0, 0, 0, 0}; for (int c = 0; c < 4; ++c) if (kk + c < D) t[c] = bhat[(int64_t)rj * D + kk + c]; rb[p] = make_float4(t[0], t[1], t[2], t[3]); }
-            }
             __syncthreads();          // previous stage fully consumed
+            // registers -> LDS transposed [k][row]
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const int r = p * 32 + srow;
@@ -114,19 +118,30 @@ __global__ void __launch_bounds__(256, 2) k_tome_match(const float* __restrict__
                 Bs[skq + 0][r] = rb[p].x; Bs[skq + 1][r] = rb[p].y; Bs[skq + 2][r] = rb[p].z; Bs[skq + 3][r] = rb[p].w;
             }
             __syncthreads();
+            if (k0 + TM_K < D) fetch(j0, k0 + TM_K);
+            else if (jt + 1 < jt_hi) fetch(j0 + TM_J, 0);
+            // MFMA A operand = b rows (j), B operand = a rows (i):  D[j][i] += sum_k b[j][k] * a[i][k]
+            // operands of step kk+2 are read from LDS while the four MFMAs of step kk run
+            float fb[2][2], fa[2][2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) fb[0][p] = Bs[lhalf][wj * 64 + p * 32 + lcol];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) fa[0][q] = As[lhalf][wi * 64 + q * 32 + lcol];
 #pragma unroll
             for (int kk = 0; kk < TM_K; kk += 2) {
-                // MFMA A operand = b rows (j), B operand = a rows (i):  D[j][i] += sum_k b[j][k] * a[i][k]
-                float fb[2], fa[2];
+                const int cur = (kk >> 1) & 1;
+                if (kk + 2 < TM_K) {
 #pragma unroll
-                for (int p = 0; p < 2; ++p) fb[p] = Bs[kk + lhalf][wj * 64 + p * 32 + lcol];
+                    for (int p = 0; p < 2; ++p) fb[cur ^ 1][p] = Bs[kk + 2 + lhalf][wj * 64 + p * 32 + lcol];
 #pragma unroll
-                for (int q = 0; q < 2; ++q) fa[q] = As[kk + lhalf][wi * 64 + q * 32 + lcol];
+                    for (int q = 0; q < 2; ++q) fa[cur ^ 1][q] = As[kk + 2 + lhalf][wi * 64 + q * 32 + lcol];
+                }
+                __builtin_amdgcn_sched_barrier(0);      // keep the reads ahead of the MFMAs they overlap with
 #pragma unroll
                 for (int p = 0; p < 2; ++p)
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
-                        acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[p], fa[q], acc[p][q], 0, 0, 0);
+                        acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[cur][p], fa[cur][q], acc[p][q], 0, 0, 0);
             }
         }
         // running max over this tile: lane owns column i = wi*64 + q*32 + lcol; rows j = (e&3) + 8*(e>>2) + 4*lhalf
@@ -266,19 +281,31 @@ __global__ void __launch_bounds__(256) k_tome_merge(const float* __restrict__ x,
 }
 
 struct TomePlan {
-    int na, nb, D;
+    int na, nb, D, Dp;
     size_t off_ahat, off_bhat, off_best, off_nmax, off_nidx, off_iota, off_keys, off_order, off_cnt, off_cur, off_off,
         off_lists, off_cub, cub_bytes, total;
 };
+
+static int tome_cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
 
 static inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
 
 static int tome_plan(int n, int C, int n_head, TomePlan* p) {
     if (n < 2 || C < 1 || n_head < 1 || C % n_head) return -1;
     p->na = (n + 1) / 2; p->nb = n / 2; p->D = C / n_head;
+    p->Dp = (p->D + TM_K - 1) / TM_K * TM_K;
     size_t o = 0;
-    p->off_ahat = o; o = al(o + (size_t)p->na * p->D * 4);
-    p->off_bhat = o; o = al(o + (size_t)(p->nb > 0 ? p->nb : 1) * p->D * 4);
+    p->off_ahat = o; o = al(o + (size_t)p->na * p->Dp * 4);
+    p->off_bhat = o; o = al(o + (size_t)(p->nb > 0 ? p->nb : 1) * p->Dp * 4);
     p->off_best = o; o = al(o + (size_t)p->na * 8);
     p->off_nmax = o; o = al(o + (size_t)p->na * 4);
     p->off_nidx = o; o = al(o + (size_t)p->na * 4);
@@ -339,15 +366,25 @@ int sttm_tome_step(const void* x_, const float* size, const int64_t* idx, int n,
     hipMemsetAsync(cnt, 0, p.off_off - p.off_cnt, stream);      // cnt and cur
     {
         int grid = (n + 3) / 4; if (grid > 8192) grid = 8192;
-        hipLaunchKernelGGL(k_tome_normalize, dim3(grid), dim3(256), 0, stream, x, n, C, n_head, p.D, ahat, bhat);
+        hipLaunchKernelGGL(k_tome_normalize, dim3(grid), dim3(256), 0, stream, x, n, C, n_head, p.D, p.Dp, ahat, bhat);
     }
     {
         const int itiles = (p.na + TM_I - 1) / TM_I;
         const int jtiles = (p.nb + TM_J - 1) / TM_J;
-        int jsplit = (512 + itiles - 1) / itiles;
-        if (jsplit > jtiles) jsplit = jtiles;
-        if (jsplit < 1) jsplit = 1;
-        hipLaunchKernelGGL(k_tome_match, dim3(itiles * jsplit), dim3(256), 0, stream, ahat, bhat, p.na, p.nb, p.D, jsplit, best);
+        // j-split: the grid is itiles*jsplit workgroups of ceil(jtiles/jsplit) tile products each, two resident per CU.
+        // Pick the split with the smallest per-CU critical path  ceil(WGs / CUs) * tiles-per-WG  (a 588-WG grid on 512
+        // slots leaves a third of the chip idle for the second round); ties go to the coarser split (fewer atomics).
+        const int n_cu = tome_cu_count();
+        int jsplit = 1;
+        long best_cost = -1;
+        for (int js = 1; js <= jtiles; ++js) {
+            const long wgs = (long)itiles * js;
+            const long per_cu = (wgs + n_cu - 1) / n_cu;
+            long cost = per_cu * ((jtiles + js - 1) / js);
+            if (per_cu < 2 && js < jtiles) cost = cost * 3 / 2;       // a lone WG per CU cannot hide its staging
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; jsplit = js; }
+        }
+        hipLaunchKernelGGL(k_tome_match, dim3(itiles * jsplit), dim3(256), 0, stream, ahat, bhat, p.na, p.nb, p.Dp, jsplit, best);
     }
     hipLaunchKernelGGL(k_tome_unpack, dim3((p.na + 255) / 256), dim3(256), 0, stream, best, p.na, nmax, nidx, iota);
     size_t cub = p.cub_bytes;
