@@ -98,7 +98,7 @@ void root_extent_host(const sttm::LevelDims& g, int I, int J, int* ah, int* aw) 
 struct Buffers {
     char* S; uint32_t* meta; double* inrm; int* rc_list;
     int32_t *edges; float* edge_sim; int32_t *edge_cnt, *cand_cnt; unsigned long long* col_mask; int32_t *frame_cnt, *bar, *colscratch;
-    int4* row_info; int32_t *grp_np, *grp_cnt, *grp_off, *members;
+    int32_t *grp_np, *grp_cnt, *grp_off, *members;
 };
 
 size_t carve_all(const Plan& p, int T, int C, int dtype, char* base, Buffers* b) {
@@ -119,7 +119,6 @@ size_t carve_all(const Plan& p, int T, int C, int dtype, char* base, Buffers* b)
     o.frame_cnt = c.take<int32_t>((size_t)T * 4);
     o.bar = c.take<int32_t>(16);
     o.colscratch = c.take<int32_t>(N * 20);
-    o.row_info = c.take<int4>(N * 16);
     o.grp_np = c.take<int32_t>(N * 4);
     o.grp_cnt = c.take<int32_t>(N * 4);
     o.grp_off = c.take<int32_t>(N * 4);
@@ -171,6 +170,15 @@ int pick_vec(int C, int dtype, const void* x, int64_t sT, int64_t sH, int64_t sW
         return v;
     }
     return 0;
+}
+
+// Group-mean workgroups per frame: enough 4-wave workgroups (T * split) to cover the chip several times over.
+int gm_split_for(int T) {
+    static const int env = [] { const char* e = getenv("STTM_GM_SPLIT"); return e ? atoi(e) : 0; }();
+    const int want = env > 0 ? env : (4096 + T - 1) / T;
+    int s = 1;
+    while (s < want && s < 64) s <<= 1;          // a power of two: the kernel masks instead of dividing
+    return s;
 }
 
 // Pack width of the row-streaming kernels (pairs, group mean): they only read / write whole [*, C] rows, so fp32 can use
@@ -254,7 +262,8 @@ int sttm_quadtree_apply(const void* v, int64_t stride_t, int64_t stride_c, int64
     ta.dtype = dtype_v; ta.vec = vec;
     ta.weighted_avg = sum_mode ? 1 : 0;
     ta.S = b.S; ta.xrows = dense ? v : nullptr;
-    ta.row_info = b.row_info; ta.members = b.members;
+    ta.frame_cnt = b.frame_cnt; ta.grp_np = b.grp_np; ta.grp_cnt = b.grp_cnt; ta.grp_off = b.grp_off; ta.members = b.members;
+    ta.meta = b.meta; ta.gm_split = gm_split_for(T);
     ta.counts = const_cast<int32_t*>(counts);
     ta.feat_out = out;
     if ((e = sttm::launch_group_mean(ta, stream)) != hipSuccess)
@@ -358,6 +367,11 @@ int sttm_quadtree_merge_async(const void* x, int64_t stride_t, int64_t stride_c,
     ta.T = T; ta.H = H; ta.W = W; ta.C = C; ta.R = p.R;
     ta.dims = p.dims;
     ta.dtype = dtype; ta.vec = row_vec(C, dtype, vec, dense, x, head_dim);
+    {
+        static const int seg_env = [] { const char* e = getenv("STTM_PAIRS_SEG"); return e ? atoi(e) : -1; }();
+        ta.pairs_seg = seg_env >= 0 ? seg_env : 16;
+        if (ta.pairs_seg > T - 1) ta.pairs_seg = T - 1 > 0 ? T - 1 : 0;
+    }
     ta.temporal_thresh = temporal_thresh;
     ta.weighted_avg = weighted_avg ? 1 : 0;
     // slow_ver has no per-head variant upstream (cross_frame_node_merging_slow ignores head_dim)
@@ -380,7 +394,7 @@ int sttm_quadtree_merge_async(const void* x, int64_t stride_t, int64_t stride_c,
         ta.dbg_wg = tw ? atoi(tw) : 0;
         ta.dbg_ticks = (tk && tk[0] == '1') ? reinterpret_cast<long long*>(b.colscratch) : nullptr;
     } ta.colscratch = b.colscratch;
-    ta.row_info = b.row_info; ta.grp_np = b.grp_np; ta.grp_cnt = b.grp_cnt; ta.grp_off = b.grp_off; ta.members = b.members;
+    ta.gm_split = gm_split_for(T); ta.grp_np = b.grp_np; ta.grp_cnt = b.grp_cnt; ta.grp_off = b.grp_off; ta.members = b.members;
     ta.counts = counts;
     ta.counts_host = counts_host; ta.seq = seq;
     ta.feat_out = feat_out; ta.npatch_out = npatch_out; ta.tlbr_out = tlbr_out;
@@ -410,8 +424,7 @@ int sttm_quadtree_merge_async(const void* x, int64_t stride_t, int64_t stride_c,
         if ((e = sttm::launch_labels_fused(ta, stream)) != hipSuccess)
             return fail(STTM_ERR_LAUNCH, "fused label kernel: %s", hipGetErrorString(e));
     } else if ((e = sttm::launch_col_labels(ta, true, stream)) != hipSuccess ||
-               (e = sttm::launch_col_labels(ta, false, stream)) != hipSuccess ||
-               (e = sttm::launch_rank(ta, stream)) != hipSuccess)
+               (e = sttm::launch_col_labels(ta, false, stream)) != hipSuccess)
         return fail(STTM_ERR_LAUNCH, "label kernels: %s", hipGetErrorString(e));
     prof_mark(3, stream);
     if ((e = sttm::launch_group_mean(ta, stream)) != hipSuccess)

@@ -51,6 +51,7 @@ struct TemporalArgs {
     // scratch
     int32_t* edges;           // [R][T-1][ecap] kept edges, packed column-local slots (dst << 16 | src), dst = earlier frame
     int ecap;
+    int pairs_seg;            // k_pairs workgroup map: frames per XCD-local segment (0 = plain t-major order)
     float* edge_sim;          // [R][T-1][ecap] similarity of each kept edge (slow_ver only, else null)
     int32_t* edge_cnt;        // [R][T-1]
     int32_t* cand_cnt;        // [R][T-1]
@@ -61,7 +62,7 @@ struct TemporalArgs {
     int dbg_wg;               // debug: which workgroup stamps
     long long* dbg_ticks;     // debug: wall_clock64 stamps of workgroup 0 at phase boundaries (null = off)
     int32_t* colscratch;      // [5*T*H*W] label arrays of columns that do not fit LDS
-    int4* row_info;           // [T*H*W] per output row: origin | leaf bit, member offset, member count, patches
+    int gm_split;             // group-mean workgroups per frame
     int32_t* grp_np;          // [T*H*W] by origin row: patches covered by the group
     int32_t* grp_cnt;         // [T*H*W] by origin row; 0 = not a survivor
     int32_t* grp_off;         // [T*H*W] by origin row
@@ -77,7 +78,6 @@ struct TemporalArgs {
 hipError_t launch_pairs(const TemporalArgs& a, hipStream_t stream);
 hipError_t launch_slow_filter(const TemporalArgs& a, hipStream_t stream);
 hipError_t launch_col_labels(const TemporalArgs& a, bool probe, hipStream_t stream);
-hipError_t launch_rank(const TemporalArgs& a, hipStream_t stream);
 bool labels_can_fuse(const TemporalArgs& a);
 hipError_t launch_labels_fused(const TemporalArgs& a, hipStream_t stream);
 hipError_t launch_group_mean(const TemporalArgs& a, hipStream_t stream);

@@ -3,9 +3,9 @@
 //   k_pairs        candidate pairs + cosine filter            (quadtree_temporal_merger.py:8-73 of the reference)
 //   k_slow_filter  slow_ver: per frame pair, similarity sort + adjacent-duplicate removal                (:75-121)
 //   k_col_labels   label propagation per root-cell column, in LDS                                      (:223-269)
-//                  <FUSED>: probe -> grid barrier -> exact replay -> groups -> grid barrier -> ranks, one launch
-//                  <PROBE> / <FINAL> + k_rank: the same code as three launches when co-residency is not guaranteed
-//   k_group_mean   per-survivor ascending-order accumulation and mean                                   (:123-171)
+//                  <FUSED>: probe -> grid barrier -> exact replay -> groups -> arrival word (N' to the host), one launch
+//                  <PROBE> / <FINAL>: the same code as two launches when co-residency is not guaranteed
+//   k_group_mean   ranks the survivors of its frame, then per-survivor ascending-order accumulation and mean (:123-171)
 //
 // All of them address nodes by their ORIGIN ROW  t*H*W + y1*W + x1  in the scratch matrix S written by the
 // spatial kernel (1x1 nodes stay in x).  Origin rows are ordered exactly like the reference's sorted node
@@ -87,7 +87,22 @@ __global__ void __launch_bounds__(256) k_pairs(TemporalArgs a) {
     int* cand = reinterpret_cast<int*>(smem_raw);     // [cap] packed (ia << 16 | ib)
     __shared__ int ncand, nkept;
     const int R = a.R;
-    const int t = blockIdx.x / R, r = blockIdx.x % R;
+    int t, r;
+    if (a.pairs_seg > 0) {
+        // XCD-aware map.  Workgroup ids go round-robin over the 8 XCDs, each with its own L2, and the node rows of
+        // (t+1, r) are read by the workgroups of pair t and of pair t+1: keep a run of consecutive frames of one root
+        // cell on ONE XCD so that the second read hits that L2 instead of going to the fabric again.
+        const int L = a.pairs_seg, nf = a.T - 1;
+        const int segs = (nf + L - 1) / L;
+        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+        const int chunk = (i / L) * 8 + xcd, pos = i % L;
+        if (chunk >= R * segs) return;
+        r = chunk / segs;
+        t = (chunk - r * segs) * L + pos;
+        if (t >= nf) return;
+    } else {
+        t = blockIdx.x / R; r = blockIdx.x % R;
+    }
     const int HW = a.H * a.W;
     const int* LA = a.rc_list + (int64_t)(t * R + r) * a.rc_stride;
     const int* LB = a.rc_list + (int64_t)((t + 1) * R + r) * a.rc_stride;
@@ -205,9 +220,15 @@ __global__ void __launch_bounds__(256) k_pairs(TemporalArgs a) {
 
 hipError_t launch_pairs(const TemporalArgs& a, hipStream_t stream) {
     if (a.T < 2) return hipSuccess;
-    const int grid = (a.T - 1) * a.R;
+    int grid = (a.T - 1) * a.R;
+    if (a.pairs_seg > 0) {
+        const int segs = (a.T - 1 + a.pairs_seg - 1) / a.pairs_seg;
+        grid = 8 * ((a.R * segs + 7) / 8) * a.pairs_seg;
+    }
     const size_t smem = sizeof(int) * (size_t)a.ecap;
-#define STTM_LAUNCH_PAIRS(TT, VV) hipLaunchKernelGGL((k_pairs<TT, VV>), dim3(grid), dim3(256), smem, stream, a)
+    static const int nt_env = [] { const char* e = getenv("STTM_PAIRS_NT"); const int v = e ? atoi(e) : 0; return (v == 64 || v == 128 || v == 256) ? v : 0; }();
+    const int nt = nt_env ? nt_env : 256;
+#define STTM_LAUNCH_PAIRS(TT, VV) hipLaunchKernelGGL((k_pairs<TT, VV>), dim3(grid), dim3(nt), smem, stream, a)
     if (a.dtype == STTM_F32) {
         if (a.vec == 8) STTM_LAUNCH_PAIRS(float, 8); else if (a.vec == 4) STTM_LAUNCH_PAIRS(float, 4); else if (a.vec == 2) STTM_LAUNCH_PAIRS(float, 2); else STTM_LAUNCH_PAIRS(float, 1);
     } else if (a.dtype == STTM_BF16) {
@@ -419,44 +440,6 @@ __device__ __forceinline__ void grid_barrier(int32_t* counter, int target, int32
     __syncthreads();
 }
 
-// rank of the survivors of frame t by one wave: rows of earlier frames (prefix) + ballot scan over the H*W origins
-__device__ __forceinline__ void rank_frame_wave(const TemporalArgs& a, int t, int prefix, int lane) {
-    const int HW = a.H * a.W, N = a.T * HW;
-    int off = prefix;
-    constexpr int NB = 4;                                       // chunks of 64 origins loaded together
-    for (int base = 0; base < HW; base += 64 * NB) {
-        int cnt[NB], np[NB], go[NB];
-        uint32_t meta[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {                          // independent loads, issued back to back
-            const int p = base + b * 64 + lane;
-            const bool in = p < HW;
-            const int origin = t * HW + (in ? p : 0);
-            cnt[b] = in ? ld_agent(a.grp_cnt + origin) : 0;
-            np[b] = ld_agent(a.grp_np + origin);
-            go[b] = ld_agent(a.grp_off + origin);
-            meta[b] = a.meta[origin];
-        }
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int p = base + b * 64 + lane;
-            const unsigned long long m = __ballot(cnt[b] > 0);
-            const int mine = off + __popcll(m & ((1ull << lane) - 1ull));
-            if (cnt[b] > 0 && mine < N) {
-                const int origin = t * HW + p;
-                const int y1 = p / a.W, x1 = p - y1 * a.W;
-                const int y2 = (int)(meta[b] >> 16), x2 = (int)(meta[b] & 0xffff);
-                const bool leaf = (y2 - y1) == 1 && (x2 - x1) == 1;
-                a.row_info[mine] = make_int4(origin | (leaf ? kLeafBit : 0), go[b], cnt[b], np[b]);
-                a.npatch_out[mine] = np[b];
-                int32_t* o = a.tlbr_out + (int64_t)mine * 5;
-                o[0] = t; o[1] = y1; o[2] = x1; o[3] = y2; o[4] = x2;
-            }
-            off += __popcll(m);
-        }
-    }
-}
-
 __device__ __forceinline__ void publish_counts(const TemporalArgs& a, int n_out) {
     a.counts[STTM_CNT_OUT] = n_out;
     if (a.counts_host) {
@@ -509,15 +492,39 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
             my_meta[k] = i < slots ? a.meta[my_row[k]] : 0u;
         }
     }
+    int cand_pre = 0;              // this column's candidate count (bookkeeping), fetched under the edge lists
     if (temporal) {
         const int nf = a.T - 1;
+        for (int t = tid; t < nf; t += nt) cand_pre += a.cand_cnt[(int64_t)r * nf + t];
         const int32_t* elist = a.edges + (int64_t)r * nf * a.ecap;
         const int total = nf * a.ecap;
         if (tid == 0) flags[0] = 0;
         __syncthreads();
-        for (int j = tid; j < total; j += nt) {
-            const int pr = elist[j];
-            if (pr != -1) cst<GMEM>(edges + atomicAdd(&flags[0], 1), pr);
+        // compaction with ONE LDS atomic per wave and round (a same-address atomic per kept edge serialises)
+        constexpr int PER = 8;
+        for (int j0 = 0; j0 < total; j0 += PER * nt) {
+            int local[PER];
+            int nv = 0;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {                 // independent, coalesced loads
+                const int j = j0 + k * nt + tid;
+                local[k] = j < total ? elist[j] : -1;
+            }
+#pragma unroll
+            for (int k = 0; k < PER; ++k) nv += local[k] != -1 ? 1 : 0;
+            int incl = nv;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int v = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += v;
+            }
+            int base = 0;
+            if (lane == 63 && incl) base = atomicAdd(&flags[0], incl);
+            base = __shfl(base, 63, 64);
+            int pos = base + incl - nv;
+#pragma unroll
+            for (int k = 0; k < PER; ++k)
+                if (local[k] != -1) cst<GMEM>(edges + pos++, local[k]);
         }
         __syncthreads();
         E = flags[0];
@@ -615,19 +622,22 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
                 const int n = cld<GMEM>(gcnt + i);
                 cst<GMEM>(aux + i, off);
                 const int row = slot_to_row(a, col, i);
-                st_agent(a.grp_off + row, col.base + off);
-                st_agent(a.grp_cnt + row, n);         // 0 for non-survivors: the rank phase keys on this
+                a.grp_off[row] = col.base + off;      // plain stores: the consumer is the next kernel
+                a.grp_cnt[row] = n;                   // 0 for non-survivors: the group-mean kernel keys on this
                 off += n;
             }
         }
         __syncthreads();
         STTM_TICK(6);
-        // survivors per frame -> frame_cnt (one atomic per (frame, column))
+        // survivors per frame -> frame_cnt (one atomic per (frame, column)); the group-mean kernel turns them into row
+        // prefixes.  `survivors` = this column's share of N'.
+        int survivors = 0;
         if (col.A <= 64) {
             for (int t = tid; t < a.T; t += nt) {
                 int c = 0;
                 for (int q = 0; q < col.A; ++q) c += cld<GMEM>(gcnt + t * col.A + q) > 0 ? 1 : 0;
                 if (c) atomicAdd(a.frame_cnt + t, c);
+                survivors += c;
             }
         } else {
             for (int t = wave; t < a.T; t += nwave) {
@@ -636,6 +646,7 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
 #pragma unroll
                 for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
                 if (lane == 0 && c) atomicAdd(a.frame_cnt + t, c);
+                if (lane == 0) survivors += c;
             }
         }
         STTM_TICK(7);
@@ -660,54 +671,50 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
             if (n > 1)
                 for (int j = 0; j < n; ++j) rk += cld<GMEM>(mem + o + j) < i ? 1 : 0;
             const int row = slot_to_row(a, col, i);
-            st_agent(out + o + rk, row | (ar == 1 ? kLeafBit : 0));
+            out[o + rk] = row | (ar == 1 ? kLeafBit : 0);
             if (r == i) {
                 int patches = ar;
                 if (n > 1) {
                     patches = 0;
                     for (int j = 0; j < n; ++j) patches += carea_ld<GMEM>(area_l, cld<GMEM>(mem + o + j));
                 }
-                st_agent(a.grp_np + row, patches);
+                a.grp_np[row] = patches;
             }
         }
         STTM_TICK(8);
-        // bookkeeping counters: one atomic per column and slot
-        if (temporal) {
-            int cand = 0;
-            for (int t = tid; t < a.T - 1; t += nt) cand += a.cand_cnt[(int64_t)r * (a.T - 1) + t];
+        // ---- bookkeeping counters and N'.  The per-wave partials meet in LDS; thread 0 adds this column's totals to the
+        // global counters, waits for exactly those atomics, and then adds (survivors << 24 | 1) to ONE 64-bit word
+        // (R < 2^24 columns, N' < 2^31): the add that completes the arrival count also returns the complete N', so the
+        // last column publishes everything to the host with no second grid barrier and no drain of the other threads'
+        // stores (their consumer is the next kernel).
+        int cand = temporal ? cand_pre : 0;
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) cand += __shfl_xor(cand, d, 64);
-            if (lane == 0 && cand) atomicAdd(a.counts + STTM_CNT_CANDIDATES, cand);
+        for (int d = 32; d >= 1; d >>= 1) {
+            nodes += __shfl_xor(nodes, d, 64); leafnodes += __shfl_xor(leafnodes, d, 64);
+            survivors += __shfl_xor(survivors, d, 64); cand += __shfl_xor(cand, d, 64);
         }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { nodes += __shfl_xor(nodes, d, 64); leafnodes += __shfl_xor(leafnodes, d, 64); }
-        if (lane == 0 && nodes) atomicAdd(a.counts + STTM_CNT_NODES, nodes);
-        if (lane == 0 && leafnodes) atomicAdd(a.counts + STTM_CNT_LEAFNODES, leafnodes);
-        if (tid == 0) {
-            if (E) atomicAdd(a.counts + STTM_CNT_EDGES, E);
-            if (r == 0) a.counts[STTM_CNT_ITERS] = K;
-        }
-    }
-    if constexpr (MODE == COL_FUSED) {
-        // ---- RANK: every column has published its groups and per-frame survivor counts ------------------------
+        __shared__ int part[4][16];
+        if (lane == 0) { part[0][wave] = nodes; part[1][wave] = leafnodes; part[2][wave] = survivors; part[3][wave] = cand; }
         STTM_TICK(9);
-        grid_barrier(a.bar + 1, R, a.counts + STTM_CNT_OVERFLOW);
-        STTM_TICK(10);
-        int* fpre = reinterpret_cast<int*>(smem_raw);          // [T] exclusive prefix of frame_cnt (LDS is free now)
-        int total = 0;
-        {
-            const int per = (a.T + nt - 1) / nt;
-            const int lo = tid * per < a.T ? tid * per : a.T, hi = lo + per < a.T ? lo + per : a.T;
-            int mine = 0;
-            for (int t = lo; t < hi; ++t) mine += ld_agent(a.frame_cnt + t);
-            int off = block_exclusive_scan(mine, wsum, &total);
-            for (int t = lo; t < hi; ++t) { fpre[t] = off; off += ld_agent(a.frame_cnt + t); }
-        }
         __syncthreads();
-        for (int t = r * nwave + wave; t < a.T; t += R * nwave) rank_frame_wave(a, t, fpre[t], lane);
+        if (tid == 0) {
+            int tot[4] = {0, 0, 0, 0};
+            for (int w = 0; w < nwave; ++w)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) tot[k] += part[k][w];
+            if (tot[0]) atomicAdd(a.counts + STTM_CNT_NODES, tot[0]);
+            if (tot[1]) atomicAdd(a.counts + STTM_CNT_LEAFNODES, tot[1]);
+            if (tot[3]) atomicAdd(a.counts + STTM_CNT_CANDIDATES, tot[3]);
+            if (E) atomicAdd(a.counts + STTM_CNT_EDGES, E);
+            if (r == 0) st_agent(a.counts + STTM_CNT_ITERS, K);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned long long* word = reinterpret_cast<unsigned long long*>(a.bar + 2);
+            const unsigned long long old = __hip_atomic_fetch_add(word, ((unsigned long long)(unsigned)tot[2] << 24) | 1ull,
+                                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            STTM_TICK(10);
+            if ((int)(old & 0xffffffull) == R - 1) publish_counts(a, (int)(old >> 24) + tot[2]);
+        }
         STTM_TICK(11);
-        if (r == 0 && tid == 0) publish_counts(a, total);
-        STTM_TICK(12);
     }
 }
 
@@ -745,48 +752,6 @@ hipError_t launch_labels_fused(const TemporalArgs& a, hipStream_t stream) {
     while (nthreads < kColThreads && nthreads * 2 <= a.max_slots) nthreads *= 2;
     if (gmem) hipLaunchKernelGGL((k_col_labels<COL_FUSED, true>), dim3(a.R), dim3(nthreads), smem, stream, a);
     else hipLaunchKernelGGL((k_col_labels<COL_FUSED, false>), dim3(a.R), dim3(nthreads), smem, stream, a);
-    return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------------------------------
-// K4: rank.  One workgroup per frame: rows of frames before it (sum of frame_cnt) + a scan of its own
-// H*W origin slots; writes row_info, tlbr and num_patches of every output row.
-// ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_rank(TemporalArgs a) {
-    __shared__ int wsum[16];
-    const int t = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-    const int HW = a.H * a.W;
-    int before = 0;
-    for (int f = tid; f < t; f += nt) before += a.frame_cnt[f];
-    int base = 0;
-    block_exclusive_scan(before, wsum, &base);
-    const int per = (HW + nt - 1) / nt;
-    const int lo = tid * per < HW ? tid * per : HW, hi = lo + per < HW ? lo + per : HW;
-    int mine = 0;
-    for (int p = lo; p < hi; ++p) mine += a.grp_cnt[t * HW + p] > 0 ? 1 : 0;
-    int tot = 0;
-    int off = base + block_exclusive_scan(mine, wsum, &tot);
-    for (int p = lo; p < hi; ++p) {
-        const int origin = t * HW + p;
-        const int cnt = a.grp_cnt[origin];
-        if (cnt > 0) {
-            const uint32_t meta = a.meta[origin];
-            const int np = a.grp_np[origin];
-            const int y1 = p / a.W, x1 = p - y1 * a.W;
-            const int y2 = (int)(meta >> 16), x2 = (int)(meta & 0xffff);
-            const bool leaf = (y2 - y1) == 1 && (x2 - x1) == 1;
-            a.row_info[off] = make_int4(origin | (leaf ? kLeafBit : 0), a.grp_off[origin], cnt, np);
-            a.npatch_out[off] = np;
-            int32_t* o = a.tlbr_out + (int64_t)off * 5;
-            o[0] = t; o[1] = y1; o[2] = x1; o[3] = y2; o[4] = x2;
-            ++off;
-        }
-    }
-    if (t == a.T - 1 && tid == 0) publish_counts(a, base + tot);
-}
-
-hipError_t launch_rank(const TemporalArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL(k_rank, dim3(a.T), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -850,6 +815,11 @@ hipError_t launch_label_edges(const int32_t* pairs, int L, int N, int32_t* rep_o
 // INPUT dtype (one rounding per add for bf16/fp16, like the reference's index_add_), then divided by
 // the member count (or the patch count when weighted_avg).
 // ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_sum_int(int v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
 template <typename T> __device__ __forceinline__ float round_to(float f);
 template <> __device__ __forceinline__ float round_to<float>(float f) { return f; }
 template <> __device__ __forceinline__ float round_to<bf16_t>(float f) { return bf16_bits_to_float(float_to_bf16_bits(f)); }
@@ -857,39 +827,82 @@ template <> __device__ __forceinline__ float round_to<f16_t>(float f) { return f
 
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256) k_group_mean(TemporalArgs a) {
+    // Workgroup (t, s): `gm_split` workgroups share frame t.  Every wave scans the frame's H*W origin slots (one ballot
+    // per 64 slots gives each survivor its rank inside the frame; rows of earlier frames are the sum of frame_cnt before it) and takes
+    // the survivors whose in-frame rank is congruent to its id, so the output order is (frame, y1, x1) with no rank pass.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
-    const int n_out = a.counts[STTM_CNT_OUT];
-    for (int row = blockIdx.x * nwave + wave; row < n_out; row += gridDim.x * nwave) {
-        const int4 info = a.row_info[row];                       // origin | leaf bit, member offset, count, patches
-        const int origin = info.x & 0x7fffffff, off = info.y, cnt = info.z;
-        const void* s0 = (info.x < 0 && a.xrows) ? a.xrows : a.S;        // 1x1 nodes were not copied out of x
-        const bool divide = a.weighted_avg || cnt > 1;
-        const float den = round_to<T>(a.weighted_avg ? (float)info.w : (float)cnt);
-        for (int c0 = lane * VEC; c0 < a.C; c0 += 64 * VEC) {
-            Pack<T, VEC> acc = load_pack<T, VEC>(s0, (int64_t)origin * a.C + c0);
-            for (int m = 1; m < cnt; ++m) {
-                const int mr = a.members[off + m];
-                const void* sm = (mr < 0 && a.xrows) ? a.xrows : a.S;
-                const Pack<T, VEC> p = load_pack<T, VEC>(sm, (int64_t)(mr & 0x7fffffff) * a.C + c0);
+    const int S = a.gm_split, t = blockIdx.x / S, s = blockIdx.x - t * S;
+    const int HW = a.H * a.W;
+    const int stride = S * nwave, me = s * nwave + wave;
+    // output rows before this frame: every wave sums frame_cnt[0..t) for itself (no LDS, no workgroup barrier)
+    int row0 = 0;
+    for (int f = lane; f < t; f += 64) row0 += a.frame_cnt[f];
+    int j0 = 0;
+    bool row0_done = false;
+    constexpr int NB = 4;                                       // 64-slot chunks whose metadata is loaded together
+    for (int base = 0; base < HW; base += 64 * NB) {
+        int cnt[NB], np[NB], go[NB];
+        uint32_t meta[NB];
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) acc.set(e, acc.get(e) + p.get(e));
-            }
-            if (divide) {
+        for (int b = 0; b < NB; ++b) {                          // independent loads, one round trip
+            const int p = base + b * 64 + lane;
+            const bool in = p < HW;
+            const int origin = t * HW + (in ? p : 0);
+            cnt[b] = in ? a.grp_cnt[origin] : 0;
+            np[b] = a.grp_np[origin];
+            go[b] = a.grp_off[origin];
+            meta[b] = a.meta[origin];
+        }
+        if (!row0_done) { row0 = wave_sum_int(row0); row0_done = true; }      // after the metadata loads were issued
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) acc.set(e, acc.get(e) / den);
+        for (int b = 0; b < NB; ++b) {
+            const unsigned long long m = __ballot(cnt[b] > 0);
+            if (m == 0ull) continue;
+            const int j = j0 + __popcll(m & ((1ull << lane) - 1ull));
+            unsigned long long sel = __ballot(cnt[b] > 0 && (j & (stride - 1)) == me);     // stride is a power of two
+            while (sel) {
+                const int l = __ffsll((long long)sel) - 1;
+                sel &= sel - 1ull;
+                const int p = base + b * 64 + l;
+                const int row = row0 + j0 + __popcll(m & ((1ull << l) - 1ull));
+                const int n = __builtin_amdgcn_readlane(cnt[b], l), off = __builtin_amdgcn_readlane(go[b], l);
+                const int patches = __builtin_amdgcn_readlane(np[b], l);
+                const uint32_t mt = (uint32_t)__builtin_amdgcn_readlane((int)meta[b], l);
+                const int origin = t * HW + p;
+                const int y1 = p / a.W, x1 = p - y1 * a.W;
+                const int y2 = (int)(mt >> 16), x2 = (int)(mt & 0xffff);
+                const bool leaf = (y2 - y1) == 1 && (x2 - x1) == 1;
+                if (a.npatch_out && lane == 0) {
+                    a.npatch_out[row] = patches;
+                    int32_t* o = a.tlbr_out + (int64_t)row * 5;
+                    o[0] = t; o[1] = y1; o[2] = x1; o[3] = y2; o[4] = x2;
+                }
+                const void* s0 = (leaf && a.xrows) ? a.xrows : a.S;          // 1x1 nodes were not copied out of x
+                const bool divide = a.weighted_avg || n > 1;
+                const float den = round_to<T>(a.weighted_avg ? (float)patches : (float)n);
+                for (int c0 = lane * VEC; c0 < a.C; c0 += 64 * VEC) {
+                    Pack<T, VEC> acc = load_pack<T, VEC>(s0, (int64_t)origin * a.C + c0);
+                    for (int k = 1; k < n; ++k) {
+                        const int mr = a.members[off + k];
+                        const void* sm = (mr < 0 && a.xrows) ? a.xrows : a.S;
+                        const Pack<T, VEC> q = load_pack<T, VEC>(sm, (int64_t)(mr & 0x7fffffff) * a.C + c0);
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) acc.set(e, acc.get(e) + q.get(e));
+                    }
+                    if (divide) {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) acc.set(e, acc.get(e) / den);
+                    }
+                    store_pack_stream<T, VEC>(a.feat_out, (int64_t)row * a.C + c0, acc);
+                }
             }
-            store_pack_stream<T, VEC>(a.feat_out, (int64_t)row * a.C + c0, acc);
+            j0 += __popcll(m);
         }
     }
 }
 
 hipError_t launch_group_mean(const TemporalArgs& a, hipStream_t stream) {
-    const int N = a.T * a.H * a.W;
-    int grid = (N + 3) / 4;
-    static int cap = -1;
-    if (cap < 0) { const char* e = getenv("STTM_GM_GRID"); cap = e ? atoi(e) : 4096; }
-    if (grid > cap) grid = cap;
-    if (grid < 1) grid = 1;
+    const int grid = a.T * a.gm_split;
 #define STTM_LAUNCH_GM(TT, VV) hipLaunchKernelGGL((k_group_mean<TT, VV>), dim3(grid), dim3(256), 0, stream, a)
     if (a.dtype == STTM_F32) {
         if (a.vec == 8) STTM_LAUNCH_GM(float, 8); else if (a.vec == 4) STTM_LAUNCH_GM(float, 4); else if (a.vec == 2) STTM_LAUNCH_GM(float, 2); else STTM_LAUNCH_GM(float, 1);

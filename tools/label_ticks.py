@@ -18,8 +18,8 @@ lib.sttm_debug_colscratch_offset.restype = ctypes.c_size_t
 lib.sttm_debug_colscratch_offset.argtypes = [ctypes.c_int] * 6
 off = lib.sttm_debug_colscratch_offset(T, H, W, C, 0, 1)
 assert off % 8 == 0 and ws.data_ptr() % 8 == 0
-names = ["start", "gathered", "probed", "barrier1", "replayed", "counted", "offsets", "frame_cnt", "filled+sorted", "pre-bar2",
-         "barrier2", "ranked", "published"]
+names = ["start", "gathered", "probed", "barrier1", "replayed", "counted", "offsets", "frame_cnt", "filled+sorted", "counters",
+         "ticket", "prefix+publish (last column only)"]
 acc = None
 for it in range(12):
     rc = lib.sttm_quadtree_merge(x.data_ptr(), x.stride(0), x.stride(1), x.stride(2), x.stride(3), T, C, H, W, 0,
@@ -28,12 +28,12 @@ for it in range(12):
     assert rc == 0
     torch.cuda.synchronize()
     pos = off // 8
-    tk = ws.view(torch.int64)[pos:pos + 13].cpu().tolist()
+    tk = ws.view(torch.int64)[pos:pos + 12].cpu().tolist()
     if it >= 2:
         d = [(b - a) / 100.0 for a, b in zip(tk[:-1], tk[1:])]
         acc = d if acc is None else [p + q for p, q in zip(acc, d)]
 n = 10
-print("fused label kernel, workgroup 0, mean of", n, "runs (us):")
+print("fused label kernel, workgroup", os.environ.get("STTM_LABEL_TICKS_WG", "0"), "mean of", n, "runs (us):")
 for nm, v in zip(names[1:], acc):
     print(f"  {nm:14s} {v / n:6.2f}")
 print(f"  total          {sum(acc) / n:6.2f}")
