@@ -60,8 +60,9 @@ __device__ __forceinline__ Column make_column(const TemporalArgs& a, int r) {
     c.Y1 = y1; c.X1 = x1; c.ah = y2 - y1; c.aw = x2 - x1; c.A = c.ah * c.aw; c.slots = a.T * c.A;
     // leaves owned by root cells 0..r-1: full root rows above + cells to the left in this root row
     c.base = a.T * (y1 * a.W + (y2 - y1) * x1);
-    c.mA = (unsigned)((0x100000000ull + (unsigned)c.A - 1) / (unsigned)c.A);
-    c.maw = (unsigned)((0x100000000ull + (unsigned)c.aw - 1) / (unsigned)c.aw);
+    // ceil(2^32 / d) for d >= 2 with 32-bit arithmetic (d == 1 is special-cased by the users)
+    c.mA = 0xffffffffu / (unsigned)c.A + 1u;
+    c.maw = 0xffffffffu / (unsigned)c.aw + 1u;
     return c;
 }
 __device__ __forceinline__ int slot_to_row(const TemporalArgs& a, const Column& c, int s) {
@@ -421,6 +422,12 @@ __device__ __forceinline__ void column_iteration(int* rep, int* rep2, const int*
     __syncthreads();
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global load and
+// store of the wave (vmcnt(0)); this one lets global loads stay in flight across the barrier.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // Grid-wide barrier among the (co-resident) column workgroups of the fused kernel.  The spin is bounded: on a
 // timeout the overflow counter is raised (the Python wrapper then fails loudly) instead of hanging the GPU.
 __device__ __forceinline__ void grid_barrier(int32_t* counter, int target, int32_t* overflow) {
@@ -479,8 +486,20 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
     const bool temporal = a.temporal_thresh > 0.f && a.T > 1;
 
     // ---- gather this column's edges (local slot ids) ------------------------------------------------------
+    // Every global load of this phase (first round of the edge lists, node boxes, candidate counts) is issued before the
+    // first workgroup barrier and consumed after it: one memory round trip for the whole phase.
+    __shared__ int ecount;
     int E = 0;
-    // node areas first: their loads fly while the edge lists are fetched
+    constexpr int PER = 8;
+    const int nf = a.T - 1;
+    const int32_t* elist = a.edges + (int64_t)r * nf * a.ecap;
+    const int total = temporal ? nf * a.ecap : 0;
+    int local[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {                         // independent, coalesced loads
+        const int j = k * nt + tid;
+        local[k] = j < total ? elist[j] : -1;
+    }
     uint32_t my_meta[4];
     int my_row[4];
     const bool few = slots <= 4 * nt;
@@ -492,24 +511,21 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
             my_meta[k] = i < slots ? a.meta[my_row[k]] : 0u;
         }
     }
-    int cand_pre = 0;              // this column's candidate count (bookkeeping), fetched under the edge lists
+    // this column's candidate count (bookkeeping only)
+    int cand_pre = (temporal && tid < nf) ? a.cand_cnt[(int64_t)r * nf + tid] : 0;
+    if (tid == 0) ecount = 0;
+    lds_barrier();                 // not __syncthreads(): that one would drain the loads just issued
     if (temporal) {
-        const int nf = a.T - 1;
-        for (int t = tid; t < nf; t += nt) cand_pre += a.cand_cnt[(int64_t)r * nf + t];
-        const int32_t* elist = a.edges + (int64_t)r * nf * a.ecap;
-        const int total = nf * a.ecap;
-        if (tid == 0) flags[0] = 0;
-        __syncthreads();
         // compaction with ONE LDS atomic per wave and round (a same-address atomic per kept edge serialises)
-        constexpr int PER = 8;
         for (int j0 = 0; j0 < total; j0 += PER * nt) {
-            int local[PER];
-            int nv = 0;
+            if (j0 > 0) {
 #pragma unroll
-            for (int k = 0; k < PER; ++k) {                 // independent, coalesced loads
-                const int j = j0 + k * nt + tid;
-                local[k] = j < total ? elist[j] : -1;
+                for (int k = 0; k < PER; ++k) {
+                    const int j = j0 + k * nt + tid;
+                    local[k] = j < total ? elist[j] : -1;
+                }
             }
+            int nv = 0;
 #pragma unroll
             for (int k = 0; k < PER; ++k) nv += local[k] != -1 ? 1 : 0;
             int incl = nv;
@@ -519,16 +535,14 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
                 if (lane >= d) incl += v;
             }
             int base = 0;
-            if (lane == 63 && incl) base = atomicAdd(&flags[0], incl);
+            if (lane == 63 && incl) base = atomicAdd(&ecount, incl);
             base = __shfl(base, 63, 64);
             int pos = base + incl - nv;
 #pragma unroll
             for (int k = 0; k < PER; ++k)
                 if (local[k] != -1) cst<GMEM>(edges + pos++, local[k]);
         }
-        __syncthreads();
-        E = flags[0];
-        __syncthreads();
+        for (int t = tid + nt; t < nf; t += nt) cand_pre += a.cand_cnt[(int64_t)r * nf + t];
     }
     // node areas (0 = no node starts at this slot): one coalesced pass over meta, reused by every later phase
     if (few) {
@@ -546,6 +560,7 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
     }
     for (int i = tid; i < slots; i += nt) { cst<GMEM>(rep + i, i); cst<GMEM>(rep2 + i, i); }
     __syncthreads();
+    E = ecount;
     STTM_TICK(1);
 
     int probe_iters = 0;
