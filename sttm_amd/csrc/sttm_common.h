@@ -183,6 +183,13 @@ __device__ __forceinline__ float dot_pack(const Pack<f16_t, VEC>& a, const Pack<
     return s;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global load and
+// store of the wave (s_waitcnt vmcnt(0)); this one lets global traffic stay in flight across the barrier.  Use it only
+// where the data exchanged through the barrier lives in LDS.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ---- wave-level reductions -----------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -422,12 +422,6 @@ __device__ __forceinline__ void column_iteration(int* rep, int* rep2, const int*
     __syncthreads();
 }
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global load and
-// store of the wave (vmcnt(0)); this one lets global loads stay in flight across the barrier.
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 // Grid-wide barrier among the (co-resident) column workgroups of the fused kernel.  The spin is bounded: on a
 // timeout the overflow counter is raised (the Python wrapper then fails loudly) instead of hanging the GPU.
 __device__ __forceinline__ void grid_barrier(int32_t* counter, int target, int32_t* overflow) {
