@@ -329,6 +329,7 @@ hipError_t launch_slow_filter(const TemporalArgs& a, hipStream_t stream) {
 // ---------------------------------------------------------------------------------------------------
 // Block-wide exclusive scan of one int per thread; returns the exclusive prefix, *total gets the sum.
 // ---------------------------------------------------------------------------------------------------
+template <bool LDS_ONLY = false>
 __device__ __forceinline__ int block_exclusive_scan(int v, int* lds_wave /*[16]*/, int* total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     int inc = v;
@@ -338,14 +339,14 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* lds_wave /*[16]*
         if (lane >= d) inc += o;
     }
     if (lane == 63) lds_wave[wave] = inc;
-    __syncthreads();
+    if constexpr (LDS_ONLY) lds_barrier(); else __syncthreads();
     int base = 0, tot = 0;
     for (int w = 0; w < nwave; ++w) {
         const int s = lds_wave[w];
         if (w < wave) base += s;
         tot += s;
     }
-    __syncthreads();
+    if constexpr (LDS_ONLY) lds_barrier(); else __syncthreads();
     *total = tot;
     return base + inc - v;
 }
@@ -391,6 +392,13 @@ template <bool GMEM> __device__ __forceinline__ int caadd(int* p, int v) {
 // One synchronous iteration of get_merge_dst_idx_safe.
 //   rep  : labels before (read only during the edge pass)       rep2 : copy of rep that receives the amin scatter
 // after the call rep == rep2 == new labels.  flags[0] = some label changed, flags[1] = not idempotent.
+// Barrier between the phases of a column workgroup.  LDS-resident columns exchange everything through LDS, so their
+// barriers must not wait for the wave's outstanding global stores (group tables, member lists: consumed by the NEXT
+// kernel) -- __syncthreads() would drain them every time.  Columns spilled to global scratch need the full barrier.
+template <bool GMEM> __device__ __forceinline__ void col_sync() {
+    if constexpr (GMEM) __syncthreads(); else lds_barrier();
+}
+
 template <bool GMEM>
 __device__ __forceinline__ void column_iteration(int* rep, int* rep2, const int* edges, int E, int slots, int* flags) {
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -403,7 +411,7 @@ __device__ __forceinline__ void column_iteration(int* rep, int* rep2, const int*
         camin<GMEM>(rep2 + d, m);
         camin<GMEM>(rep2 + s, m);
     }
-    __syncthreads();
+    col_sync<GMEM>();
     int changed = 0;
     for (int i = tid; i < slots; i += nt) {
         const int v = cld<GMEM>(rep2 + cld<GMEM>(rep2 + i));
@@ -411,7 +419,7 @@ __device__ __forceinline__ void column_iteration(int* rep, int* rep2, const int*
         cst<GMEM>(rep + i, v);
     }
     if (changed) flags[0] = 1;
-    __syncthreads();
+    col_sync<GMEM>();
     int bad = 0;
     for (int i = tid; i < slots; i += nt) {
         const int v = cld<GMEM>(rep + i);
@@ -419,7 +427,7 @@ __device__ __forceinline__ void column_iteration(int* rep, int* rep2, const int*
         if (cld<GMEM>(rep + v) != v) bad = 1;
     }
     if (bad) flags[1] = 1;
-    __syncthreads();
+    col_sync<GMEM>();
 }
 
 // Grid-wide barrier among the (co-resident) column workgroups of the fused kernel.  The spin is bounded: on a
@@ -553,7 +561,7 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
         }
     }
     for (int i = tid; i < slots; i += nt) { cst<GMEM>(rep + i, i); cst<GMEM>(rep2 + i, i); }
-    __syncthreads();
+    col_sync<GMEM>();
     E = ecount;
     STTM_TICK(1);
 
@@ -566,7 +574,7 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
         while (true) {
             column_iteration<GMEM>(rep, rep2, edges, E, slots, flags);
             const int changed = flags[0], bad = flags[1];
-            __syncthreads();
+            col_sync<GMEM>();
             if (!bad) mask |= 1ull << it;
             ++it;
             if (!changed) break;                 // fixed point: stable => idempotent from here on
@@ -592,7 +600,7 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) m &= __shfl_xor(m, d, 64);
             if (lane == 0) wmask[wave] = m;
-            __syncthreads();
+            col_sync<GMEM>();
             unsigned long long all = ~0ull;
             for (int w = 0; w < nwave; ++w) all &= wmask[w];
             K = all ? __ffsll((long long)all) : kMaxProbeIters;      // lowest set bit index + 1
@@ -601,7 +609,7 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
             if (MODE == COL_FINAL || K < probe_iters - 1) {
                 if (MODE == COL_FUSED) {
                     for (int i = tid; i < slots; i += nt) { cst<GMEM>(rep + i, i); cst<GMEM>(rep2 + i, i); }
-                    __syncthreads();
+                    col_sync<GMEM>();
                 }
                 for (int it = 0; it < K; ++it) column_iteration<GMEM>(rep, rep2, edges, E, slots, flags);
             }
@@ -611,13 +619,13 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
         int* gcnt = rep2;
         const int HW = a.H * a.W;
         for (int i = tid; i < slots; i += nt) cst<GMEM>(gcnt + i, 0);
-        __syncthreads();
+        col_sync<GMEM>();
         int nodes = 0, leafnodes = 0;
         for (int i = tid; i < slots; i += nt) {
             const int ar = carea_ld<GMEM>(area_l, i);
             if (ar) { caadd<GMEM>(gcnt + cld<GMEM>(rep + i), 1); ++nodes; leafnodes += ar == 1 ? 1 : 0; }
         }
-        __syncthreads();
+        col_sync<GMEM>();
         STTM_TICK(5);
         // offsets of the groups inside this column's slice of `members` (exclusive scan over slots)
         {
@@ -626,7 +634,7 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
             int mine = 0;
             for (int i = lo; i < hi; ++i) mine += cld<GMEM>(gcnt + i);
             int tot = 0;
-            int off = block_exclusive_scan(mine, wsum, &tot);
+            int off = block_exclusive_scan<!GMEM>(mine, wsum, &tot);
             for (int i = lo; i < hi; ++i) {
                 const int n = cld<GMEM>(gcnt + i);
                 cst<GMEM>(aux + i, off);
@@ -636,7 +644,7 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
                 off += n;
             }
         }
-        __syncthreads();
+        col_sync<GMEM>();
         STTM_TICK(6);
         // survivors per frame -> frame_cnt (one atomic per (frame, column)); the group-mean kernel turns them into row
         // prefixes.  `survivors` = this column's share of N'.
@@ -666,7 +674,7 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
                 cst<GMEM>(mem + pos, i);
             }
         }
-        __syncthreads();
+        col_sync<GMEM>();
         int32_t* out = a.members + col.base;
         // node-parallel ordering: every node ranks itself inside its group's (unordered) list -- O(group size) per node,
         // balanced over the threads -- and publishes its origin row at that rank; the representative totals the patches
@@ -705,7 +713,7 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
         __shared__ int part[4][16];
         if (lane == 0) { part[0][wave] = nodes; part[1][wave] = leafnodes; part[2][wave] = survivors; part[3][wave] = cand; }
         STTM_TICK(9);
-        __syncthreads();
+        col_sync<GMEM>();
         if (tid == 0) {
             int tot[4] = {0, 0, 0, 0};
             for (int w = 0; w < nwave; ++w)
