@@ -74,7 +74,7 @@ def quadtree_merge_raw(x, threshold, temporal_thresh, root_level, weighted_avg, 
             int(bool(slow_ver)), ws.data_ptr(), ws.numel(), feat.data_ptr(), npatch.data_ptr(), tlbr.data_ptr(), counts.data_ptr(),
             host.data_ptr(), seq, stream.cuda_stream)
         _lib.raise_for(rc)
-        # Output sizes are data dependent, so the host must learn N' -- but only N': the rank kernel publishes the
+        # Output sizes are data dependent, so the host must learn N' -- but only N': the label kernel publishes the
         # counts into pinned memory and we spin on that, returning while the feature gather is still running.
         if lib.sttm_wait_counts(host.data_ptr(), seq, 2_000_000) != 0:
             host.copy_(counts, non_blocking=True)  # fallback: classic D2H + stream sync
