@@ -15,7 +15,7 @@ State read by the hook is the same: `self.image_token_start_index`, `self.image_
 import torch
 
 from . import patch_hooks
-from .quadtree_interface import get_quadtree_features
+from .quadtree_interface import get_quadtree_features, get_quadtree_features_into
 from .tome_interface import get_tome_features
 
 _UNIMPLEMENTED = {
@@ -69,7 +69,8 @@ def _qwen2_forward_with_merge(self, input_ids=None, attention_mask=None, positio
                 hidden_states, position_ids, idx = patch_hooks.quadtree_merge_llava(
                     hidden_states, position_ids, start, length, T, type(self).sttm_merge_fn,
                     self.sa_tree_thresh, self.sa_tree_temporal_thresh, self.sa_tree_root_level, self.sa_tree_weighted_avg,
-                    slow_ver=self.sttm_slow_ver, head_dim=head_dim)
+                    slow_ver=self.sttm_slow_ver, head_dim=head_dim,
+                    merge_into_fn=_fused_merge_fn(type(self)))
             else:
                 hidden_states, position_ids, idx = patch_hooks.tome_merge(
                     hidden_states, position_ids, start, length, T, type(self).sttm_tome_fn, self.sa_prune_ratio, self.sa_tome_ver)
@@ -127,7 +128,7 @@ def _qwen2vl_forward_with_merge(self, input_ids=None, attention_mask=None, posit
                 hidden_states, position_ids, _cache_pos, idx = patch_hooks.quadtree_merge_qwen2vl(
                     hidden_states, position_ids, start, length, T, H, W, type(self).sttm_merge_fn,
                     self.sa_tree_thresh, self.sa_tree_temporal_thresh, self.sa_tree_root_level, self.sa_tree_weighted_avg,
-                    slow_ver=self.sttm_slow_ver)
+                    slow_ver=self.sttm_slow_ver, merge_into_fn=_fused_merge_fn(type(self)))
             else:
                 hidden_states, position_ids, idx = patch_hooks.tome_merge(
                     hidden_states, position_ids, start, length, T, type(self).sttm_tome_fn, self.sa_prune_ratio,
@@ -156,6 +157,12 @@ def _qwen2vl_model_class():
         return getattr(m, "Qwen2VLTextModel", None) or getattr(m, "Qwen2VLModel", None)
     except Exception:  # noqa: BLE001
         return None
+
+
+def _fused_merge_fn(cls):
+    """Fused slice -> merge -> concat (the kernels write the merged rows into the new hidden-state buffer) is used
+    whenever the merge function is the library's own; an injected `sttm_merge_fn` (tests) takes the plain path."""
+    return get_quadtree_features_into if cls.sttm_merge_fn is get_quadtree_features else None
 
 
 def replace_qwen2_with_quadtree_attn(sa_start_layer_idx=0, sa_tree_thresh=0.90, sa_tree_temporal_thresh=-1.0,

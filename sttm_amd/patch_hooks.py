@@ -22,29 +22,45 @@ def split_prompt(hidden_states, start, length):
     return hidden_states[:, :start], hidden_states[:, start:end], hidden_states[:, end:]
 
 
+def _merge_concat(hidden_states, start, length, video, merge_fn, merge_into_fn, args, kwargs):
+    """system ++ merge(video) ++ instruction  (quadtree_attn_monkey_patch.py:101-105).
+
+    With `merge_into_fn` (sttm_amd.get_quadtree_features_into) the merged rows are written by the kernels straight into
+    the new hidden-state buffer: no intermediate [N', C] tensor and no copy of it by torch.cat.
+    The new buffer has the OLD sequence length (N' <= length), the result is its leading [:, :S'] view."""
+    sys_f, _, inst_f = split_prompt(hidden_states, start, length)
+    if merge_into_fn is None or hidden_states.size(0) != 1:
+        feat, npatch, tlbr = merge_fn(video, *args, **kwargs)
+        return torch.cat([sys_f, feat.unsqueeze(0), inst_f], dim=1), tlbr
+    new = torch.empty_like(hidden_states, memory_format=torch.contiguous_format)
+    new[:, :start].copy_(sys_f)
+    feat, npatch, tlbr = merge_into_fn(new[0, start:], video, *args, **kwargs)
+    n = feat.size(0)
+    new[:, start + n:start + n + inst_f.size(1)].copy_(inst_f)
+    return new[:, :start + n + inst_f.size(1)], tlbr
+
+
 def quadtree_merge_llava(hidden_states, position_ids, start, length, T, merge_fn, threshold, temporal_thresh,
-                         root_level, weighted_avg, slow_ver=False, head_dim=None):
+                         root_level, weighted_avg, slow_ver=False, head_dim=None, merge_into_fn=None):
     """Returns (merged hidden_states [1, S', C], position_ids[:, :S'], merged_token_1d_idx)."""
-    sys_f, vis_f, inst_f = split_prompt(hidden_states, start, length)
     H = W = int(math.sqrt(length // T))                                   # :97 (needs mm_newline_position=no_token)
-    video = _video_view(vis_f[0], T, H, W)
-    feat, _, tlbr = merge_fn(video, threshold, temporal_thresh, root_level, weighted_avg,
-                             slow_ver=slow_ver, head_dim=head_dim)
+    video = _video_view(hidden_states[0, start:start + length], T, H, W)
+    merged, tlbr = _merge_concat(hidden_states, start, length, video, merge_fn, merge_into_fn,
+                                 (threshold, temporal_thresh, root_level, weighted_avg),
+                                 dict(slow_ver=slow_ver, head_dim=head_dim))
     idx = tlbr[:, 0] * (H * W) + tlbr[:, 1] * W + tlbr[:, 2]              # :103-104
-    merged = torch.cat([sys_f, feat.unsqueeze(0), inst_f], dim=1)          # :105
     return merged, position_ids[:, :merged.size(1)], idx                   # :114 (truncate, not gather)
 
 
 def quadtree_merge_qwen2vl(hidden_states, position_ids, start, length, T, H, W, merge_fn, threshold, temporal_thresh,
-                           root_level, weighted_avg, slow_ver=False):
+                           root_level, weighted_avg, slow_ver=False, merge_into_fn=None):
     """position_ids is the 3-D mRoPE tensor [3, B, S]; the visual part is GATHERED by the merged index (:109-113).
     Returns (merged hidden_states, position_ids, cache_position, merged_token_1d_idx)."""
-    sys_f, vis_f, inst_f = split_prompt(hidden_states, start, length)
     end = start + length
-    video = _video_view(vis_f[0], T, H, W)
-    feat, _, tlbr = merge_fn(video, threshold, temporal_thresh, root_level, weighted_avg, slow_ver=slow_ver)
+    video = _video_view(hidden_states[0, start:end], T, H, W)
+    merged, tlbr = _merge_concat(hidden_states, start, length, video, merge_fn, merge_into_fn,
+                                 (threshold, temporal_thresh, root_level, weighted_avg), dict(slow_ver=slow_ver))
     idx = tlbr[:, 0] * (H * W) + tlbr[:, 1] * W + tlbr[:, 2]
-    merged = torch.cat([sys_f, feat.unsqueeze(0), inst_f], dim=1)
     vis_pos = position_ids[:, :, start:end][:, :, idx.long()]
     pos = torch.cat([position_ids[:, :, :start], vis_pos, position_ids[:, :, end:]], dim=-1)
     cache_position = torch.arange(merged.size(1), device=merged.device, dtype=torch.int)      # :114

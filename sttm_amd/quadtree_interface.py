@@ -26,7 +26,8 @@ def _counts_host(device):
     return buf
 
 
-def quadtree_merge_raw(x, threshold, temporal_thresh, root_level, weighted_avg, head_dim, slow_ver=False, return_ctx=False):
+def quadtree_merge_raw(x, threshold, temporal_thresh, root_level, weighted_avg, head_dim, slow_ver=False, return_ctx=False,
+                       feat_dest=None):
     """Launch the merge of one video and return the worst-case-sized outputs plus the host counts.
     x: logical [T, C, H, W] CUDA tensor (any strides; channels-last views run zero-copy)."""
     if not x.is_cuda:
@@ -62,7 +63,14 @@ def quadtree_merge_raw(x, threshold, temporal_thresh, root_level, weighted_avg, 
                       torch.empty(_lib.CNT_SLOTS, dtype=torch.int32, device=dev))
             _ws_cache[skey] = cached
         ws, counts = cached
-        feat = torch.empty((N, C), dtype=x.dtype, device=dev)
+        if feat_dest is None:
+            feat = torch.empty((N, C), dtype=x.dtype, device=dev)
+        else:
+            # caller-owned destination (fused slice -> merge -> concat): rows [0, N') of it receive the merged features
+            feat = feat_dest
+            if (feat.dim() != 2 or feat.size(1) != C or feat.dtype != x.dtype or feat.device != dev
+                    or not feat.is_contiguous() or feat.data_ptr() % 16):
+                raise ValueError("feat_dest must be a contiguous, 16-byte aligned [rows, C] tensor of the input's dtype and device")
         npatch = torch.empty(N, dtype=torch.int32, device=dev)
         tlbr = torch.empty((N, 5), dtype=torch.int32, device=dev)
         host = _counts_host(dev)
@@ -220,3 +228,21 @@ def get_quadtree_features(_video_feature, threshold, temporal_thresh=-1.0, root_
     out_cos = _apply_side_tensor(cos, ctx, root_level, pos_emb_weighted_avg)
     out_sin = _apply_side_tensor(sin, ctx, root_level, pos_emb_weighted_avg)
     return feat[:n], npatch[:n], tlbr[:n], (out_cos[:n], out_sin[:n])
+
+
+
+def get_quadtree_features_into(dest, _video_feature, threshold, temporal_thresh=-1.0, root_level=0, weighted_avg=False,
+                               slow_ver=False, head_dim=None):
+    """get_quadtree_features with a caller-owned destination: the merged features are written to dest[:N'] directly
+    (dest: contiguous [rows >= T*H*W, C] tensor, e.g. a row window of the NEW hidden-state buffer), so the caller's
+    `torch.cat([system, merged, instruction])` (quadtree_attn_monkey_patch.py:105) needs no copy of the merged rows.
+    Nothing of `dest` beyond row N' is written.  dest must not overlap the input.
+    Returns (dest[:N'], num_patches [N'], tlbr [N', 5])."""
+    T, C, H, W = _video_feature.shape
+    if dest.dim() != 2 or dest.size(0) < T * H * W:
+        raise ValueError("dest must be [rows, C] with room for the worst case (rows >= T*H*W): N' is only known "
+                         "after the kernels have run")
+    feat, npatch, tlbr, cnt = quadtree_merge_raw(_video_feature, threshold, temporal_thresh, root_level, weighted_avg,
+                                                 head_dim, slow_ver, feat_dest=dest)
+    n = cnt[_lib.CNT_OUT]
+    return feat[:n], npatch[:n], tlbr[:n]

@@ -1,0 +1,107 @@
+"""GPU tests of the decoder-hook glue on the device path: the fused slice -> merge -> concat must give
+exactly what the reference's three steps give (quadtree_attn_monkey_patch.py:88-117, qwen2vl :88-115), and the patched
+Qwen2 forward must run end to end on the GPU through the HIP library."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _prompt(T, C, H, W, dtype, n_sys=7, n_inst=11, seed=0):
+    from sttm_amd.synth import synth_video
+    dev = torch.device("cuda:0")
+    vid = synth_video(T, C, H, W, seed=seed, dtype=dtype, device=dev)                     # [T, C, H, W]
+    vis = vid.permute(0, 2, 3, 1).reshape(1, T * H * W, C)
+    g = torch.Generator(device="cpu").manual_seed(seed + 1)
+    sys_f = torch.randn(1, n_sys, C, generator=g).to(dev, dtype)
+    inst_f = torch.randn(1, n_inst, C, generator=g).to(dev, dtype)
+    return torch.cat([sys_f, vis, inst_f], dim=1).contiguous(), n_sys, T * H * W
+
+
+@pytest.mark.parametrize("T,C,H,W,dtype", [(8, 256, 14, 14, torch.float32), (6, 512, 14, 14, torch.bfloat16),
+                                           (4, 128, 18, 26, torch.float32)])
+def test_fused_concat_equals_three_step_hook_llava(T, C, H, W, dtype):
+    from sttm_amd import get_quadtree_features, get_quadtree_features_into, patch_hooks
+    if H != W:
+        pytest.skip("the LLaVA hook assumes square frames")
+    hs, start, length = _prompt(T, C, H, W, dtype)
+    pos = torch.arange(hs.shape[1], device=hs.device).unsqueeze(0)
+    keep = hs.clone()
+    a = patch_hooks.quadtree_merge_llava(hs, pos, start, length, T, get_quadtree_features, 0.85, 0.55, 1, False)
+    b = patch_hooks.quadtree_merge_llava(hs, pos, start, length, T, get_quadtree_features, 0.85, 0.55, 1, False,
+                                         merge_into_fn=get_quadtree_features_into)
+    assert torch.equal(hs, keep)                                   # the input hidden states are not modified
+    assert b[0].shape == a[0].shape and b[0].shape[1] < hs.shape[1]
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("T,C,H,W,dtype", [(8, 256, 14, 14, torch.float32), (4, 128, 18, 26, torch.float32),
+                                           (5, 256, 20, 36, torch.bfloat16)])
+def test_fused_concat_equals_three_step_hook_qwen2vl(T, C, H, W, dtype):
+    from sttm_amd import get_quadtree_features, get_quadtree_features_into, patch_hooks
+    hs, start, length = _prompt(T, C, H, W, dtype, seed=3)
+    S = hs.shape[1]
+    pos = torch.arange(3 * S, device=hs.device).reshape(3, 1, S)
+    a = patch_hooks.quadtree_merge_qwen2vl(hs, pos, start, length, T, H, W, get_quadtree_features, 0.85, 0.60, 0, False)
+    b = patch_hooks.quadtree_merge_qwen2vl(hs, pos, start, length, T, H, W, get_quadtree_features, 0.85, 0.60, 0, False,
+                                           merge_into_fn=get_quadtree_features_into)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+
+
+def test_into_rejects_short_destination_and_leaves_tail_untouched():
+    from sttm_amd import get_quadtree_features, get_quadtree_features_into
+    from sttm_amd.synth import synth_video
+    dev = torch.device("cuda:0")
+    x = synth_video(6, 128, 14, 14, seed=5, device=dev)
+    N = 6 * 196
+    with pytest.raises(ValueError):
+        get_quadtree_features_into(torch.empty((N - 1, 128), device=dev), x, 0.85, 0.55, 1)
+    dest = torch.full((N + 5, 128), 7.0, device=dev)
+    f, n, t = get_quadtree_features_into(dest, x, 0.85, 0.55, 1)
+    ef, en, et = get_quadtree_features(x, 0.85, 0.55, 1)
+    assert f.data_ptr() == dest.data_ptr() and torch.equal(f, ef) and torch.equal(n, en) and torch.equal(t, et)
+    assert torch.all(dest[f.shape[0]:] == 7.0)                     # nothing beyond row N' is written
+
+
+def test_patched_qwen2_forward_runs_on_device_and_matches_oracle_glue():
+    transformers = pytest.importorskip("transformers")
+    from transformers import Qwen2Config
+    from transformers.models.qwen2.modeling_qwen2 import Qwen2Model
+    from oracle import sttm_oracle as O
+    from sttm_amd import monkey_patch_interface as MPI
+    from sttm_amd import patch_hooks
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    C, T = 64, 4
+    cfg = Qwen2Config(vocab_size=64, hidden_size=C, intermediate_size=128, num_hidden_layers=3, num_attention_heads=4,
+                      num_key_value_heads=2, max_position_embeddings=4096, attn_implementation="sdpa")
+    model = Qwen2Model(cfg).eval().to(dev)
+    hs, start, length = _prompt(T, C, 14, 14, torch.float32)
+    try:
+        MPI.replace_qwen2_by_sparse_attn("quadtree", sa_start_layer_idx=1, sa_tree_thresh=0.85, sa_tree_temporal_thresh=0.55,
+                                         sa_tree_root_level=1)
+        model.image_token_start_index = torch.tensor(start)
+        model.image_token_length = torch.tensor(length)
+        model.num_frame = torch.tensor(T)
+        with torch.inference_mode():
+            out = model(inputs_embeds=hs, use_cache=False).last_hidden_state
+            # the same forward by hand, with the CPU oracle doing the merge on the layer-0 output
+            pos = torch.arange(hs.shape[1], device=dev).unsqueeze(0)
+            pe = model.rotary_emb(hs, pos)
+            h = model.layers[0](hs, attention_mask=None, position_embeddings=pe, position_ids=pos)
+            hm, pm, idx = patch_hooks.quadtree_merge_llava(h.cpu(), pos.cpu(), start, length, T, O.get_quadtree_features,
+                                                           0.85, 0.55, 1, False)
+            hm, pm = hm.to(dev), pm.to(dev)
+            pe = model.rotary_emb(hm, pm)
+            for layer in model.layers[1:]:
+                hm = layer(hm, attention_mask=None, position_embeddings=pe, position_ids=pm)
+            ref = model.norm(hm)
+        assert torch.equal(model.merged_token_1d_idx.cpu().long(), idx.long())
+        assert out.shape == ref.shape and out.shape[1] < hs.shape[1]
+        assert torch.allclose(out, ref, atol=2e-5)
+    finally:
+        MPI.restore_qwen2()
+        if "sttm_merge_fn" in Qwen2Model.__dict__:
+            del Qwen2Model.sttm_merge_fn
