@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STTM_ABI_VERSION 2
+#define STTM_ABI_VERSION 3
 
 #define STTM_F32 0
 #define STTM_BF16 1
@@ -154,6 +154,20 @@ size_t sttm_tome_workspace_bytes(int n, int C, int n_head);
 int sttm_tome_step(const void* x, const float* size, const int64_t* idx, int n, int C, int n_head, int r, int dtype,
                    void* workspace, size_t workspace_bytes, void* x_out, float* size_out, int64_t* idx_out,
                    float* node_max_out, int32_t* node_idx_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Upstream 2-D pooling of the projected vision tokens: replaces LlavaMetaForCausalLM.get_2dPool
+ * (llava/model/llava_arch.py:173-198): x [T, H*W, C] row-major tokens -> out [T, OH*OW, C], same dtype.
+ *   mode STTM_POOL_AVERAGE / STTM_POOL_MAX : stride x stride windows, OH = H / stride (floor)   (:185-188)
+ *   mode STTM_POOL_BILINEAR                : F.interpolate(size = ceil(H / stride)), align_corners = False (:189-192)
+ * sttm_pool2d_out_side gives OH (or OW) for one side; stride == 1 is the caller's identity case (:174-175).
+ * Enqueued on `stream`, no workspace, no host synchronisation.
+ * ------------------------------------------------------------------------------------------------ */
+#define STTM_POOL_AVERAGE 0
+#define STTM_POOL_MAX 1
+#define STTM_POOL_BILINEAR 2
+int sttm_pool2d_out_side(int side, int stride, int mode);
+int sttm_pool2d(const void* x, int T, int H, int W, int C, int dtype, int mode, int stride, void* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -31,6 +31,8 @@ SIGNATURES = {
     "sttm_merge_dst_idx": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "sttm_tome_workspace_bytes": (_sz, [_i, _i, _i]),
     "sttm_tome_step": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sttm_pool2d_out_side": (_i, [_i, _i, _i]),
+    "sttm_pool2d": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
 }
 
 _lib = None
@@ -50,7 +52,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.sttm_abi_version() != 2:
+    if lib.sttm_abi_version() != 3:
         raise RuntimeError("libsttm_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -434,6 +434,24 @@ int sttm_quadtree_merge_async(const void* x, int64_t stride_t, int64_t stride_c,
     return STTM_OK;
 }
 
+int sttm_pool2d_out_side(int side, int stride, int mode) {
+    if (side < 1 || stride < 1 || mode < STTM_POOL_AVERAGE || mode > STTM_POOL_BILINEAR) return fail(STTM_ERR_ARG, "bad side/stride/mode");
+    if (stride == 1) return side;
+    return mode == STTM_POOL_BILINEAR ? (side + stride - 1) / stride : side / stride;
+}
+
+int sttm_pool2d(const void* x, int T, int H, int W, int C, int dtype, int mode, int stride, void* out, void* stream_) {
+    if (!x || !out || T < 1 || H < 1 || W < 1 || C < 1 || stride < 1) return fail(STTM_ERR_ARG, "bad pointer or shape");
+    if (dtype < 0 || dtype > 2) return fail(STTM_ERR_ARG, "bad dtype");
+    if (mode < STTM_POOL_AVERAGE || mode > STTM_POOL_BILINEAR) return fail(STTM_ERR_ARG, "Unexpected mm_spatial_pool_mode: %d", mode);
+    if (dtype != STTM_F32 && (C & 1)) return fail(STTM_ERR_UNSUPPORTED, "16-bit inputs need an even channel count");
+    const int OH = sttm_pool2d_out_side(H, stride, mode), OW = sttm_pool2d_out_side(W, stride, mode);
+    if (OH < 1 || OW < 1) return fail(STTM_ERR_ARG, "pooling window larger than the grid");
+    hipError_t e = sttm::launch_pool2d(x, out, T, H, W, C, OH, OW, stride, mode, dtype, reinterpret_cast<hipStream_t>(stream_));
+    if (e != hipSuccess) return fail(STTM_ERR_LAUNCH, "pool2d kernel: %s", hipGetErrorString(e));
+    return STTM_OK;
+}
+
 // debug helper (not in the public header): byte offset of the column scratch inside the workspace
 size_t sttm_debug_colscratch_offset(int T, int H, int W, int C, int dtype, int root_level) {
     Plan p;

@@ -83,6 +83,8 @@ hipError_t launch_labels_fused(const TemporalArgs& a, hipStream_t stream);
 hipError_t launch_group_mean(const TemporalArgs& a, hipStream_t stream);
 bool col_labels_use_gmem(const TemporalArgs& a);
 
+hipError_t launch_pool2d(const void* x, void* out, int T, int H, int W, int C, int OH, int OW, int stride, int mode, int dtype,
+                         hipStream_t stream);
 hipError_t launch_label_edges(const int32_t* pairs, int L, int N, int32_t* rep_out, int32_t* rep2, int32_t* emin,
                               int32_t* iters_out, hipStream_t stream);
 

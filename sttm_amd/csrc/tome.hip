@@ -227,6 +227,8 @@ __global__ void __launch_bounds__(256) k_tome_merge(const float* __restrict__ x,
                                                     const int* __restrict__ order, const int* __restrict__ off,
                                                     int* __restrict__ lists, float* __restrict__ x_out,
                                                     float* __restrict__ size_out, int64_t* __restrict__ idx_out) {
+#pragma clang fp contract(off)      // x*size is rounded before it is added, like the reference's mul then scatter-add
+
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     const int n_out = n - r;
     for (int row = blockIdx.x * nwave + wave; row < n_out; row += gridDim.x * nwave) {
@@ -265,14 +267,14 @@ __global__ void __launch_bounds__(256) k_tome_merge(const float* __restrict__ x,
         float stot = sb;
         for (int m = 0; m < cnt; ++m) {
             const int atok = 2 * order[lists[o + m]];
-            stot = __fadd_rn(stot, size ? size[atok] : 1.f);
+            stot = stot + (size ? size[atok] : 1.f);
         }
         for (int c = lane; c < C; c += 64) {
-            float acc = __fmul_rn(x[(int64_t)tok * C + c], sb);          // no fma contraction: the reference rounds x*size
+            float acc = x[(int64_t)tok * C + c] * sb;     // plain operators: the __fmul_rn/__fadd_rn wrappers fuse once inlined
             for (int m = 0; m < cnt; ++m) {
                 const int atok = 2 * order[lists[o + m]];
                 const float sa = size ? size[atok] : 1.f;
-                acc = __fadd_rn(acc, __fmul_rn(x[(int64_t)atok * C + c], sa));
+                acc = acc + x[(int64_t)atok * C + c] * sa;
             }
             x_out[(int64_t)row * C + c] = acc / stot;
         }

@@ -53,3 +53,25 @@ def quadtree_kwargs(meta):
     thr = kw.pop("threshold")
     kw.pop("pos", None)            # channel count of the position embeddings stored in the fixture
     return thr, kw
+
+
+# ---- upstream pooling vectors (tests/golden/pool_*.npz, made by make_golden_pool.py) -------------------------
+POOL_GOLDEN = sorted(glob.glob(os.path.join(GOLDEN_DIR, "pool_*.npz")))
+
+
+def load_pool_case(path):
+    z = np.load(path)
+    meta = json.loads(str(z["meta"]))
+    return meta, _t(z["x"], meta["dtype"]), _t(z["y"], meta["dtype"])
+
+
+def pool_close_enough(out, exp, meta):
+    """max pooling / stride 1: exact; bf16: one ulp; fp32: 2e-6 absolute on unit-variance inputs (the ATen kernels may
+    contract multiplies and adds differently from the one-rounding-per-operation restatement)."""
+    assert out.shape == exp.shape and out.dtype == exp.dtype
+    if meta["mode"] == "max" or meta["stride"] == 1:
+        return torch.equal(out, exp)
+    if exp.dtype == torch.bfloat16:
+        d = (out.view(torch.int16).int() - exp.view(torch.int16).int()).abs()
+        return int(d.max()) <= 1
+    return float((out - exp).abs().max()) <= 2e-6

@@ -1,0 +1,69 @@
+"""GPU parity tests of the upstream 2-D pooling kernel (sttm_amd.upstream.get_2dPool -> sttm_pool2d) against the vectors the
+reference's get_2dPool produced and against the CPU oracle at the production shape."""
+import os
+
+import pytest
+import torch
+
+from tests._golden import POOL_GOLDEN as GOLDEN, load_pool_case, pool_close_enough as close_enough
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=os.path.basename)
+def test_pool_golden_vectors(path):
+    from sttm_amd.upstream import get_2dPool
+    meta, x, y = load_pool_case(path)
+    out = get_2dPool(x.to(DEV), stride=meta["stride"], width=meta.get("width", -1), mode=meta["mode"],
+                     num_patches_per_side=meta["side"])
+    assert out.shape[1] == meta["out_tokens"]
+    assert close_enough(out.cpu(), y, meta)
+
+
+@pytest.mark.parametrize("T,side,C,stride,mode,dtype", [
+    (16, 27, 3584, 2, "bilinear", torch.bfloat16),       # LLaVA-Video: 27x27 SigLIP patches -> 14x14, Qwen2-7B width
+    (8, 27, 1024, 2, "bilinear", torch.float32),
+    (4, 27, 896, 2, "average", torch.float16),
+    (4, 24, 1024, 3, "max", torch.bfloat16),
+    (3, 27, 50, 2, "bilinear", torch.float32),           # narrow rows: 2-wide packs
+    (3, 9, 7, 2, "average", torch.float32),              # odd channel count: scalar packs
+])
+def test_pool_matches_oracle_bit_exactly(T, side, C, stride, mode, dtype):
+    """The kernel follows the oracle's arithmetic order (float32, one rounding per operation): results are identical."""
+    from oracle import pool_oracle as P
+    from sttm_amd.upstream import get_2dPool
+    g = torch.Generator().manual_seed(T * 1000 + C)
+    x = torch.randn(T, side * side, C, generator=g).to(dtype)
+    exp = P.get_2dpool(x, stride, side, side, mode)
+    out = get_2dPool(x.to(DEV), stride=stride, width=side, mode=mode)
+    assert out.dtype == dtype and out.shape == exp.shape
+    assert torch.equal(out.cpu(), exp)
+
+
+def test_pool_interface_behaviour():
+    from sttm_amd.upstream import get_2dPool
+    x = torch.randn(2, 81, 8, device=DEV)
+    assert get_2dPool(x, stride=1) is x                                  # llava_arch.py:174-175
+    with pytest.raises(ValueError, match="Unexpected mm_spatial_pool_mode"):
+        get_2dPool(x, stride=2, mode="nearest")
+    with pytest.raises(RuntimeError):
+        get_2dPool(x, stride=2, width=10)                                # 10*10 != 81: the reference's view() fails too
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        get_2dPool(x.cpu(), stride=2)
+
+
+def test_pool_then_merge_pipeline_shapes():
+    """27x27 projector tokens -> 14x14 -> STTM merge: the producer and the hot path chained on the device."""
+    from sttm_amd import get_quadtree_features
+    from sttm_amd.upstream import get_2dPool
+    T, C = 8, 256
+    g = torch.Generator().manual_seed(5)
+    base = torch.randn(1, 729, C, generator=g)
+    x = (base + 0.05 * torch.randn(T, 729, C, generator=g)).to(DEV)      # near-static clip: the temporal stage merges a lot
+    pooled = get_2dPool(x, stride=2, mode="bilinear", num_patches_per_side=27)
+    assert pooled.shape == (T, 196, C)
+    video = pooled.reshape(T, 14, 14, C).permute(0, 3, 1, 2)
+    f, n, t = get_quadtree_features(video, 0.85, 0.55, 1)
+    assert f.shape[0] == n.shape[0] == t.shape[0] and 0 < f.shape[0] < T * 196
+    assert int(n.sum()) == T * 196
