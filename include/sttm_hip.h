@@ -166,8 +166,16 @@ int sttm_tome_step(const void* x, const float* size, const int64_t* idx, int n, 
 #define STTM_POOL_AVERAGE 0
 #define STTM_POOL_MAX 1
 #define STTM_POOL_BILINEAR 2
+#define STTM_POOL_NEAREST 3   /* only through sttm_resize_nearest */
 int sttm_pool2d_out_side(int side, int stride, int mode);
 int sttm_pool2d(const void* x, int T, int H, int W, int C, int dtype, int mode, int stride, void* out, void* stream);
+
+/*
+ * Nearest-neighbour resize of every frame to OH x OW: the "pyrd" baseline's F.interpolate(video, size=(s, s))
+ * (token_merging_monkey_patch/pyrd_attn_monkey_patch.py:99-102; default mode "nearest").
+ * x [T, H*W, C] -> out [T, OH*OW, C], same dtype; a pure row gather (exact).
+ */
+int sttm_resize_nearest(const void* x, int T, int H, int W, int C, int dtype, int OH, int OW, void* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -78,3 +78,19 @@ def get_2dpool(image_feature, stride=2, height=None, width=None, mode="bilinear"
         raise ValueError(f"Unexpected mm_spatial_pool_mode: {mode}")
     out = torch.from_numpy(np.ascontiguousarray(out.astype(np.float32))).to(image_feature.dtype)
     return out.reshape(T, oh * ow, C)
+
+
+def resize_nearest(tokens, height, width, size):
+    """The "pyrd" baseline's F.interpolate(video, size=size) (default mode "nearest",
+    token_merging_monkey_patch/pyrd_attn_monkey_patch.py:99-102) on [T, height*width, C] tokens:
+    src = min(floor(dst * (in / out)), in - 1) with a float32 scale and product (ATen nearest_neighbor_compute_source_index)."""
+    T, n_tok, C = tokens.shape
+    oh, ow = int(size[0]), int(size[1])
+
+    def src(n_in, n_out):
+        scale = np.float32(n_in) / np.float32(n_out)
+        i = np.floor(np.arange(n_out, dtype=np.float32) * scale).astype(np.int64)
+        return np.minimum(i, n_in - 1)
+    ys, xs = src(height, oh), src(width, ow)
+    rows = torch.from_numpy((ys[:, None] * width + xs[None, :]).reshape(-1))
+    return tokens[:, rows, :]

@@ -33,6 +33,7 @@ SIGNATURES = {
     "sttm_tome_step": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sttm_pool2d_out_side": (_i, [_i, _i, _i]),
     "sttm_pool2d": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "sttm_resize_nearest": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
 }
 
 _lib = None

@@ -452,6 +452,15 @@ int sttm_pool2d(const void* x, int T, int H, int W, int C, int dtype, int mode, 
     return STTM_OK;
 }
 
+int sttm_resize_nearest(const void* x, int T, int H, int W, int C, int dtype, int OH, int OW, void* out, void* stream_) {
+    if (!x || !out || T < 1 || H < 1 || W < 1 || C < 1 || OH < 1 || OW < 1) return fail(STTM_ERR_ARG, "bad pointer or shape");
+    if (dtype < 0 || dtype > 2) return fail(STTM_ERR_ARG, "bad dtype");
+    if (dtype != STTM_F32 && (C & 1)) return fail(STTM_ERR_UNSUPPORTED, "16-bit inputs need an even channel count");
+    hipError_t e = sttm::launch_pool2d(x, out, T, H, W, C, OH, OW, 1, STTM_POOL_NEAREST, dtype, reinterpret_cast<hipStream_t>(stream_));
+    if (e != hipSuccess) return fail(STTM_ERR_LAUNCH, "resize kernel: %s", hipGetErrorString(e));
+    return STTM_OK;
+}
+
 // debug helper (not in the public header): byte offset of the column scratch inside the workspace
 size_t sttm_debug_colscratch_offset(int T, int H, int W, int C, int dtype, int root_level) {
     Plan p;

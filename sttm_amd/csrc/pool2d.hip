@@ -44,7 +44,13 @@ __global__ void __launch_bounds__(256) k_pool2d(PoolArgs a) {
         const int64_t frame = (int64_t)t * a.H * a.W;
         const int c0 = pk * VEC;
         Pack<T, VEC> res;
-        if (a.mode == STTM_POOL_BILINEAR) {
+        if (a.mode == STTM_POOL_NEAREST) {
+            // F.interpolate(size=...) default mode: src = min(floor(dst * (in / out)), in - 1), float32 product
+            int sy = (int)floorf((float)oy * a.sh), sx = (int)floorf((float)ox * a.sw);
+            sy = sy < a.H - 1 ? sy : a.H - 1;
+            sx = sx < a.W - 1 ? sx : a.W - 1;
+            res = load_pack<T, VEC>(a.x, (frame + (int64_t)sy * a.W + sx) * a.C + c0);
+        } else if (a.mode == STTM_POOL_BILINEAR) {
             int y0, y1, x0, x1;
             float h0, h1, w0, w1;
             bilinear_tap(a.sh, oy, a.H, y0, y1, h0, h1);

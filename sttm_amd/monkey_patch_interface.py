@@ -21,7 +21,6 @@ from .tome_interface import get_tome_features
 _UNIMPLEMENTED = {
     "quadtree-abl-pos": "position-embedding ablation (quadtree_attn_monkey_patch_for_abl_pos.py)",
     "octree": "octree ablation (octree_utils.py)",
-    "pyrd": "fixed-size F.interpolate pyramid baseline",
     "quadtree_vis": "visualisation variant",
     "dycoke": "DyCoke baseline",
     "dycoke-stage1": "DyCoke stage-1 baseline",
@@ -62,7 +61,17 @@ def _qwen2_forward_with_merge(self, input_ids=None, attention_mask=None, positio
     position_embeddings = self.rotary_emb(hidden_states, position_ids)
     merged = False
     for i, layer in enumerate(self.layers[: self.config.num_hidden_layers]):
-        if prefilling and not merged and i == self.sa_start_layer_idx and getattr(self, "image_token_length", None) is not None:
+        if (prefilling and self.sttm_pattern == "pyrd" and i in self.sa_pyrd_llm_idxs
+                and getattr(self, "image_token_length", None) is not None):
+            # fixed-size pyramid baseline: may fire at several layers, each shrinking the frames further
+            start, length, T = _item(self.image_token_start_index), _item(self.image_token_length), _item(self.num_frame)
+            hidden_states, position_ids, new_len = patch_hooks.pyrd_resize(
+                hidden_states, position_ids, start, length, T, self.sa_pyrd_idx2size[i], type(self).sttm_resize_fn)
+            self.image_token_length = torch.tensor(new_len)              # like the reference (:101): persists on the module
+            position_embeddings = self.rotary_emb(hidden_states, position_ids)
+            mask_map = {k: None for k in mask_map}
+        elif (prefilling and not merged and self.sttm_pattern != "pyrd" and i == self.sa_start_layer_idx
+                and getattr(self, "image_token_length", None) is not None):
             start, length, T = _item(self.image_token_start_index), _item(self.image_token_length), _item(self.num_frame)
             if self.sttm_pattern == "quadtree":
                 head_dim = layer.self_attn.head_dim if self.sim_per_head else None
@@ -185,6 +194,22 @@ def replace_qwen2_with_quadtree_attn(sa_start_layer_idx=0, sa_tree_thresh=0.90, 
     cls.forward = _qwen2_forward_with_merge
 
 
+def replace_qwen2_with_pyrd_attn(sa_pyrd_loc_list=[2], sa_pyrd_size_list=[10], **kwargs):
+    """pyrd_attn_monkey_patch.py:167-173: resize every frame to size x size (nearest) before the listed decoder layers."""
+    print("Replace Qwen2 attention path by Pyramid token merging [sttm_amd / MI355X]")
+    assert len(sa_pyrd_loc_list) == len(sa_pyrd_size_list)
+    cls = _qwen2_model_class()
+    cls.sttm_pattern = "pyrd"
+    cls.sa_pyrd_llm_idxs = list(sa_pyrd_loc_list)
+    cls.sa_pyrd_idx2size = {sa_pyrd_loc_list[i]: sa_pyrd_size_list[i] for i in range(len(sa_pyrd_loc_list))}
+    if not hasattr(cls, "sttm_resize_fn"):
+        from .upstream import resize_nearest
+        cls.sttm_resize_fn = staticmethod(resize_nearest)
+    if not hasattr(cls, "_sttm_original_forward"):
+        cls._sttm_original_forward = cls.forward
+    cls.forward = _qwen2_forward_with_merge
+
+
 def replace_qwen2_with_tome_attn(sa_start_layer_idx=0, sa_prune_ratio=0.50, sa_tome_ver="frame", **kwargs):
     print("Replace Qwen2 attention path by ToMe token merging [sttm_amd / MI355X]")
     cls = _qwen2_model_class()
@@ -252,6 +277,8 @@ def replace_qwen2_by_sparse_attn(pattern_name, **kwargs):
     elif pattern_name == "tome":
         replace_qwen2_with_tome_attn(**kwargs)
         replace_qwen2vl_with_tome_attn(**kwargs)
+    elif pattern_name == "pyrd":
+        replace_qwen2_with_pyrd_attn(**kwargs)
     elif pattern_name in _UNIMPLEMENTED:
         raise NotImplementedError(f"{pattern_name} ({_UNIMPLEMENTED[pattern_name]}) is outside the MI355X hot-path build")
     else:

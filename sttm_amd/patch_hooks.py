@@ -77,3 +77,16 @@ def tome_merge(hidden_states, position_ids, start, length, T, merge_fn, prune_ra
     feat, token_idx = merge_fn(video, prune_ratio, tome_ver)
     merged = torch.cat([sys_f, feat.unsqueeze(0), inst_f], dim=1)
     return merged, position_ids[..., :merged.size(1)], token_idx
+
+
+def pyrd_resize(hidden_states, position_ids, start, length, T, tgt_size, resize_fn):
+    """The "pyrd" baseline (pyrd_attn_monkey_patch.py:88-112): every frame of the visual slice is resized to
+    tgt_size x tgt_size with F.interpolate's default (nearest) mode.  resize_fn(tokens [T, H*W, C], H, W, (s, s)).
+    Returns (hidden_states, position_ids[:, :S'], new visual length)."""
+    sys_f, vis_f, inst_f = split_prompt(hidden_states, start, length)
+    H = int(math.sqrt(length // T))                                       # :97
+    C = vis_f.shape[-1]
+    resized = resize_fn(vis_f[0].reshape(T, H * H, C), H, H, (tgt_size, tgt_size))
+    resized = resized.reshape(1, T * tgt_size * tgt_size, C)
+    merged = torch.cat([sys_f, resized, inst_f], dim=1)                   # :103
+    return merged, position_ids[:, :merged.size(1)], resized.size(1)       # :101, :108

@@ -48,3 +48,24 @@ def get_2dPool(image_feature, stride=2, width=-1, mode="bilinear", num_patches_p
                              out.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream)
     _lib.raise_for(rc)
     return out
+
+
+def resize_nearest(tokens, height, width, size):
+    """F.interpolate(video, size=size) with the default mode ("nearest"), on channels-last tokens:
+    tokens [T, height*width, C] -> [T, size[0]*size[1], C] (the "pyrd" baseline, pyrd_attn_monkey_patch.py:99-102)."""
+    if not tokens.is_cuda:
+        raise RuntimeError("sttm_amd runs on the GPU only: the input must be a CUDA (ROCm) tensor; there is no CPU fallback")
+    if tokens.dtype not in _DTYPE_CODE:
+        raise NotImplementedError(f"dtype {tokens.dtype} is not supported (float32, bfloat16, float16)")
+    T, n_tok, C = tokens.shape
+    if height * width != n_tok:
+        raise RuntimeError("token count %d is not %d x %d" % (n_tok, height, width))
+    oh, ow = int(size[0]), int(size[1])
+    x = tokens.contiguous()
+    out = torch.empty((T, oh * ow, C), dtype=x.dtype, device=x.device)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        rc = lib.sttm_resize_nearest(x.data_ptr(), T, height, width, C, _DTYPE_CODE[x.dtype], oh, ow, out.data_ptr(),
+                                     torch.cuda.current_stream(x.device).cuda_stream)
+    _lib.raise_for(rc)
+    return out

@@ -67,3 +67,49 @@ def test_pool_then_merge_pipeline_shapes():
     f, n, t = get_quadtree_features(video, 0.85, 0.55, 1)
     assert f.shape[0] == n.shape[0] == t.shape[0] and 0 < f.shape[0] < T * 196
     assert int(n.sum()) == T * 196
+
+
+@pytest.mark.parametrize("T,side,C,tgt,dtype", [(8, 14, 1024, 10, torch.float32), (6, 14, 3584, 7, torch.bfloat16),
+                                               (4, 27, 256, 14, torch.float16), (3, 10, 34, 13, torch.float32)])
+def test_resize_nearest_matches_oracle_exactly(T, side, C, tgt, dtype):
+    from oracle import pool_oracle as P
+    from sttm_amd.upstream import resize_nearest
+    g = torch.Generator().manual_seed(tgt)
+    x = torch.randn(T, side * side, C, generator=g).to(dtype)
+    out = resize_nearest(x.to(DEV), side, side, (tgt, tgt))
+    assert torch.equal(out.cpu(), P.resize_nearest(x, side, side, (tgt, tgt)))
+
+
+def test_pyrd_pattern_runs_on_device():
+    transformers = pytest.importorskip("transformers")
+    import torch.nn.functional as F
+    from transformers import Qwen2Config
+    from transformers.models.qwen2.modeling_qwen2 import Qwen2Model
+    from sttm_amd import monkey_patch_interface as MPI
+    torch.manual_seed(0)
+    C, T, start = 64, 4, 5
+    cfg = Qwen2Config(vocab_size=64, hidden_size=C, intermediate_size=128, num_hidden_layers=3, num_attention_heads=4,
+                      num_key_value_heads=2, max_position_embeddings=4096, attn_implementation="sdpa")
+    model = Qwen2Model(cfg).eval().to(DEV)
+    hs = torch.randn(1, start + T * 196 + 9, C, device=DEV)
+    try:
+        MPI.replace_qwen2_by_sparse_attn("pyrd", sa_pyrd_loc_list=[1], sa_pyrd_size_list=[10])
+        model.image_token_start_index = torch.tensor(start)
+        model.image_token_length = torch.tensor(T * 196)
+        model.num_frame = torch.tensor(T)
+        with torch.inference_mode():
+            out = model(inputs_embeds=hs, use_cache=False).last_hidden_state
+            pos = torch.arange(hs.shape[1], device=DEV).unsqueeze(0)
+            pe = model.rotary_emb(hs, pos)
+            h = model.layers[0](hs, attention_mask=None, position_embeddings=pe, position_ids=pos)
+            vis = h[0, start:start + T * 196].reshape(T, 14, 14, C).permute(0, 3, 1, 2)
+            r = F.interpolate(vis, size=(10, 10)).permute(0, 2, 3, 1).reshape(1, T * 100, C)
+            h = torch.cat([h[:, :start], r, h[:, start + T * 196:]], dim=1)
+            pos = pos[:, :h.shape[1]]
+            pe = model.rotary_emb(h, pos)
+            for layer in model.layers[1:]:
+                h = layer(h, attention_mask=None, position_embeddings=pe, position_ids=pos)
+            ref = model.norm(h)
+        assert out.shape == ref.shape and torch.allclose(out, ref, atol=2e-5)
+    finally:
+        MPI.restore_qwen2()

@@ -57,7 +57,7 @@ def test_tome_hook():
 
 
 def test_installer_names_and_errors():
-    for name in ("quadtree-abl-pos", "octree", "pyrd", "quadtree_vis", "dycoke", "dycoke-stage1", "nonsense"):
+    for name in ("quadtree-abl-pos", "octree", "quadtree_vis", "dycoke", "dycoke-stage1", "nonsense"):
         with pytest.raises(NotImplementedError):
             MPI.replace_qwen2_by_sparse_attn(name)
 
@@ -160,3 +160,50 @@ def test_hook_on_gpu_uses_the_hip_path():
                                                       0.85, 0.55, 1, False)
     ref, _, ridx = patch_hooks.quadtree_merge_llava(hs, pos, start, length, 6, O.get_quadtree_features, 0.85, 0.55, 1, False)
     assert torch.equal(idx.cpu(), ridx) and float((out.cpu() - ref).abs().max()) <= 1e-5
+
+
+def test_pyrd_pattern_forward_matches_manual_layers():
+    """"pyrd" baseline (pyrd_attn_monkey_patch.py:88-112, installer :167-173): frames resized (nearest) before the listed
+    layers, possibly more than once; checked against the manual forward with torch's own F.interpolate."""
+    transformers = pytest.importorskip("transformers")
+    import torch.nn.functional as F
+    from transformers import Qwen2Config
+    from transformers.models.qwen2.modeling_qwen2 import Qwen2Model
+    from oracle import pool_oracle as PO
+    torch.manual_seed(0)
+    C, T = 32, 4
+    cfg = Qwen2Config(vocab_size=64, hidden_size=C, intermediate_size=64, num_hidden_layers=4, num_attention_heads=4,
+                      num_key_value_heads=2, max_position_embeddings=4096, attn_implementation="sdpa")
+    model = Qwen2Model(cfg).eval()
+    hs, start, length = _prompt(T=T, C=C)
+    try:
+        Qwen2Model.sttm_resize_fn = staticmethod(PO.resize_nearest)             # inject the CPU oracle
+        MPI.replace_qwen2_by_sparse_attn("pyrd", sa_pyrd_loc_list=[1, 3], sa_pyrd_size_list=[10, 6])
+        assert Qwen2Model.sa_pyrd_idx2size == {1: 10, 3: 6}
+        model.image_token_start_index = torch.tensor(start)
+        model.image_token_length = torch.tensor(length)
+        model.num_frame = torch.tensor(T)
+        with torch.inference_mode():
+            out = model(inputs_embeds=hs, use_cache=False).last_hidden_state
+            assert int(model.image_token_length) == T * 36                       # persists, like the reference (:101)
+            pos = torch.arange(hs.shape[1]).unsqueeze(0)
+            h, cur = hs, length
+            for i, layer in enumerate(model.layers):
+                if i in (1, 3):
+                    tgt = {1: 10, 3: 6}[i]
+                    side = int((cur // T) ** 0.5)
+                    vis = h[0, start:start + cur].reshape(T, side, side, C).permute(0, 3, 1, 2)
+                    r = F.interpolate(vis, size=(tgt, tgt)).permute(0, 2, 3, 1).reshape(1, T * tgt * tgt, C)
+                    h = torch.cat([h[:, :start], r, h[:, start + cur:]], dim=1)
+                    cur = T * tgt * tgt
+                    pos = pos[:, :h.shape[1]]
+                pe = model.rotary_emb(h, pos)
+                h = layer(h, attention_mask=None, position_embeddings=pe, position_ids=pos)
+            ref = model.norm(h)
+        assert out.shape == ref.shape and out.shape[1] == hs.shape[1] - length + T * 36
+        assert torch.allclose(out, ref, atol=1e-5)
+    finally:
+        MPI.restore_qwen2()
+        for name in ("sttm_resize_fn",):
+            if name in Qwen2Model.__dict__:
+                delattr(Qwen2Model, name)
