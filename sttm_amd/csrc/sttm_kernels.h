@@ -15,7 +15,7 @@ struct SpatialArgs {
     int sum_mode;             // weighted_avg: sum-pool pyramid
     int n_head;               // 0 = whole-vector cosine; > 0 = per-head cosine averaged over n_head heads
     int head_lanes;           // head_dim / vec: adjacent lanes that own one head (power of two <= 64)
-    int pipeline;             // opt-in: persistent double-buffered 3-level kernel (measured slower on MI355X)
+    int pipeline;             // opt-in: persistent software-pipelined 3-level kernel (measured slower on MI355X)
     int dbg_mode;             // ablation (sttm_debug_spatial_ms only): 1 = stop after the statistics, 2 = loads + pooling only
     int leaves_in_x;          // x is a dense [T*H*W, C] matrix: 1x1 nodes are NOT copied to S (consumers read x)
     // outputs
