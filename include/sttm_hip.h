@@ -177,6 +177,21 @@ int sttm_pool2d(const void* x, int T, int H, int W, int C, int dtype, int mode, 
  */
 int sttm_resize_nearest(const void* x, int T, int H, int W, int C, int dtype, int OH, int OW, void* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * DyCoke stage-1 pruning: replaces dycoke_ttm (token_merging_utils/dycoke_merger.py:8-83).  float32 only.
+ *   x [T*P, C] row-major tokens (P tokens per frame), k = int((1 - prune_ratio) * P) tokens kept per pruned frame.
+ *   Pass 1: frames (2j, 2j+1) -- frame 2j+1 keeps its k least similar tokens (per-token cosine, ascending order).
+ *   Pass 2: frames (4j, 4j+2), 4j < T-4 -- frame 4j+2 keeps its k least similar tokens w.r.t. frame 4j.
+ *   out [rows, C] / out_idx [rows] int64 flat token ids, rows = sttm_dycoke_out_rows(T, P, k) (known in advance).
+ * T < 5 is an argument error (the reference's torch.stack of an empty list raises there too).
+ * Ties between equal similarities go to the smaller token id (torch.topk leaves that order unspecified).
+ * Enqueued on `stream` without any host synchronisation; workspace >= sttm_dycoke_workspace_bytes(T, P, k).
+ * ------------------------------------------------------------------------------------------------ */
+size_t sttm_dycoke_workspace_bytes(int T, int P, int k);
+int64_t sttm_dycoke_out_rows(int T, int P, int k);
+int sttm_dycoke_ttm(const void* x, int T, int P, int C, int dtype, int k, void* workspace, size_t workspace_bytes,
+                    void* out, int64_t* out_idx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

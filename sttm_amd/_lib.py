@@ -33,6 +33,9 @@ SIGNATURES = {
     "sttm_tome_step": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sttm_pool2d_out_side": (_i, [_i, _i, _i]),
     "sttm_pool2d": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "sttm_dycoke_workspace_bytes": (_sz, [_i, _i, _i]),
+    "sttm_dycoke_out_rows": (ctypes.c_int64, [_i, _i, _i]),
+    "sttm_dycoke_ttm": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "sttm_resize_nearest": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
 }
 

@@ -461,6 +461,42 @@ int sttm_resize_nearest(const void* x, int T, int H, int W, int C, int dtype, in
     return STTM_OK;
 }
 
+static inline int dycoke_pairs(int T) { return T / 2 + (T > 4 ? (T - 4 + 3) / 4 : 0); }
+
+size_t sttm_dycoke_workspace_bytes(int T, int P, int k) {
+    if (T < 1 || P < 1 || k < 0) { fail(STTM_ERR_ARG, "bad T/P/k"); return 0; }
+    const size_t np = (size_t)dycoke_pairs(T);
+    return ((np * P * 4 + 255) / 256) * 256 + ((np * (size_t)(k > 0 ? k : 1) * 4 + 255) / 256) * 256 + 256;
+}
+
+int64_t sttm_dycoke_out_rows(int T, int P, int k) {
+    int64_t rows = 0;
+    const int n1 = T / 2;
+    for (int f = 0; f < T; ++f) {
+        const bool pruned = (f & 1) || ((f & 3) == 2 && f - 2 < T - 4);
+        rows += pruned ? k : P;
+    }
+    (void)n1;
+    return rows;
+}
+
+int sttm_dycoke_ttm(const void* x, int T, int P, int C, int dtype, int k, void* workspace, size_t workspace_bytes,
+                    void* out, int64_t* out_idx, void* stream_) {
+    if (!x || !workspace || !out || !out_idx || P < 1 || C < 1 || k < 0 || k > P) return fail(STTM_ERR_ARG, "bad pointer or shape");
+    if (T < 5) return fail(STTM_ERR_ARG, "stack expects a non-empty TensorList (dycoke_ttm needs at least 5 frames)");
+    if (dtype != STTM_F32) return fail(STTM_ERR_UNSUPPORTED, "dycoke_ttm runs in float32 only");
+    if (P > 2048) return fail(STTM_ERR_UNSUPPORTED, "more than 2048 tokens per frame");
+    if (workspace_bytes < sttm_dycoke_workspace_bytes(T, P, k)) return fail(STTM_ERR_ARG, "workspace too small");
+    const size_t np = (size_t)dycoke_pairs(T);
+    char* ws = reinterpret_cast<char*>(workspace);
+    float* sim = reinterpret_cast<float*>(ws);
+    int32_t* keep = reinterpret_cast<int32_t*>(ws + ((np * P * 4 + 255) / 256) * 256);
+    hipError_t e = sttm::launch_dycoke(reinterpret_cast<const float*>(x), T, P, C, k, sim, keep, reinterpret_cast<float*>(out), out_idx,
+                                       reinterpret_cast<hipStream_t>(stream_));
+    if (e != hipSuccess) return fail(STTM_ERR_LAUNCH, "dycoke kernels: %s", hipGetErrorString(e));
+    return STTM_OK;
+}
+
 // debug helper (not in the public header): byte offset of the column scratch inside the workspace
 size_t sttm_debug_colscratch_offset(int T, int H, int W, int C, int dtype, int root_level) {
     Plan p;

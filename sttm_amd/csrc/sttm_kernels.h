@@ -85,6 +85,8 @@ bool col_labels_use_gmem(const TemporalArgs& a);
 
 hipError_t launch_pool2d(const void* x, void* out, int T, int H, int W, int C, int OH, int OW, int stride, int mode, int dtype,
                          hipStream_t stream);
+hipError_t launch_dycoke(const float* x, int T, int P, int C, int k, float* sim, int32_t* keep, float* out, int64_t* out_idx,
+                         hipStream_t stream);
 hipError_t launch_label_edges(const int32_t* pairs, int L, int N, int32_t* rep_out, int32_t* rep2, int32_t* emin,
                               int32_t* iters_out, hipStream_t stream);
 

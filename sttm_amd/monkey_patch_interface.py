@@ -22,8 +22,7 @@ _UNIMPLEMENTED = {
     "quadtree-abl-pos": "position-embedding ablation (quadtree_attn_monkey_patch_for_abl_pos.py)",
     "octree": "octree ablation (octree_utils.py)",
     "quadtree_vis": "visualisation variant",
-    "dycoke": "DyCoke baseline",
-    "dycoke-stage1": "DyCoke stage-1 baseline",
+    "dycoke": "DyCoke with stage-2 KV-cache pruning during decoding",
 }
 
 
@@ -80,6 +79,9 @@ def _qwen2_forward_with_merge(self, input_ids=None, attention_mask=None, positio
                     self.sa_tree_thresh, self.sa_tree_temporal_thresh, self.sa_tree_root_level, self.sa_tree_weighted_avg,
                     slow_ver=self.sttm_slow_ver, head_dim=head_dim,
                     merge_into_fn=_fused_merge_fn(type(self)))
+            elif self.sttm_pattern == "dycoke-stage1":
+                hidden_states, position_ids, idx = patch_hooks.dycoke_merge(
+                    hidden_states, position_ids, start, length, T, type(self).sttm_dycoke_fn, self.sa_prune_ratio)
             else:
                 hidden_states, position_ids, idx = patch_hooks.tome_merge(
                     hidden_states, position_ids, start, length, T, type(self).sttm_tome_fn, self.sa_prune_ratio, self.sa_tome_ver)
@@ -138,6 +140,10 @@ def _qwen2vl_forward_with_merge(self, input_ids=None, attention_mask=None, posit
                     hidden_states, position_ids, start, length, T, H, W, type(self).sttm_merge_fn,
                     self.sa_tree_thresh, self.sa_tree_temporal_thresh, self.sa_tree_root_level, self.sa_tree_weighted_avg,
                     slow_ver=self.sttm_slow_ver, merge_into_fn=_fused_merge_fn(type(self)))
+            elif self.sttm_pattern == "dycoke-stage1":
+                hidden_states, position_ids, idx = patch_hooks.dycoke_merge(
+                    hidden_states, position_ids, start, length, T, type(self).sttm_dycoke_fn, self.sa_prune_ratio,
+                    gather_positions=True)
             else:
                 hidden_states, position_ids, idx = patch_hooks.tome_merge(
                     hidden_states, position_ids, start, length, T, type(self).sttm_tome_fn, self.sa_prune_ratio,
@@ -192,6 +198,32 @@ def replace_qwen2_with_quadtree_attn(sa_start_layer_idx=0, sa_tree_thresh=0.90, 
     if not hasattr(cls, "_sttm_original_forward"):
         cls._sttm_original_forward = cls.forward
     cls.forward = _qwen2_forward_with_merge
+
+
+def _install_dycoke(cls, forward, sa_start_layer_idx, sa_prune_ratio):
+    cls.sttm_pattern = "dycoke-stage1"
+    cls.sa_start_layer_idx = sa_start_layer_idx
+    cls.sa_prune_ratio = sa_prune_ratio
+    if not hasattr(cls, "sttm_dycoke_fn"):
+        from .dycoke_merger import dycoke_ttm
+        cls.sttm_dycoke_fn = staticmethod(dycoke_ttm)
+    if not hasattr(cls, "_sttm_original_forward"):
+        cls._sttm_original_forward = cls.forward
+    cls.forward = forward
+
+
+def replace_qwen2_with_dycoke_stage1_attn(sa_start_layer_idx=0, sa_prune_ratio=0.7, **kwargs):
+    """dycoke_stage1_attn_monkey_patch.py:165-169."""
+    print("Replace Qwen2 attention path by DyCoke stage-1 pruning [sttm_amd / MI355X]")
+    _install_dycoke(_qwen2_model_class(), _qwen2_forward_with_merge, sa_start_layer_idx, sa_prune_ratio)
+
+
+def replace_qwen2vl_with_dycoke_stage1_attn(sa_start_layer_idx=0, sa_prune_ratio=0.7, **kwargs):
+    """token_merging_qwen2vl_monkey_patch/dycoke_stage1_attn_monkey_patch.py:165-168."""
+    cls = _qwen2vl_model_class()
+    if cls is None:
+        return
+    _install_dycoke(cls, _qwen2vl_forward_with_merge, sa_start_layer_idx, sa_prune_ratio)
 
 
 def replace_qwen2_with_pyrd_attn(sa_pyrd_loc_list=[2], sa_pyrd_size_list=[10], **kwargs):
@@ -279,6 +311,9 @@ def replace_qwen2_by_sparse_attn(pattern_name, **kwargs):
         replace_qwen2vl_with_tome_attn(**kwargs)
     elif pattern_name == "pyrd":
         replace_qwen2_with_pyrd_attn(**kwargs)
+    elif pattern_name == "dycoke-stage1":
+        replace_qwen2_with_dycoke_stage1_attn(**kwargs)
+        replace_qwen2vl_with_dycoke_stage1_attn(**kwargs)
     elif pattern_name in _UNIMPLEMENTED:
         raise NotImplementedError(f"{pattern_name} ({_UNIMPLEMENTED[pattern_name]}) is outside the MI355X hot-path build")
     else:

@@ -90,3 +90,19 @@ def pyrd_resize(hidden_states, position_ids, start, length, T, tgt_size, resize_
     resized = resized.reshape(1, T * tgt_size * tgt_size, C)
     merged = torch.cat([sys_f, resized, inst_f], dim=1)                   # :103
     return merged, position_ids[:, :merged.size(1)], resized.size(1)       # :101, :108
+
+
+def dycoke_merge(hidden_states, position_ids, start, length, T, ttm_fn, prune_ratio, gather_positions=False):
+    """DyCoke stage-1 hook: LLaVA (dycoke_stage1_attn_monkey_patch.py:88-107) truncates position_ids; Qwen2-VL
+    (token_merging_qwen2vl_monkey_patch/dycoke_stage1_attn_monkey_patch.py:88-108, gather_positions=True) gathers the 3-D
+    mRoPE ids of the kept tokens.  ttm_fn(tokens [T*P, C], T, prune_ratio) -> (tokens, flat ids)."""
+    sys_f, vis_f, inst_f = split_prompt(hidden_states, start, length)
+    end = start + length
+    feat, idx = ttm_fn(vis_f[0], T, prune_ratio)
+    merged = torch.cat([sys_f, feat.unsqueeze(0), inst_f], dim=1)
+    if gather_positions:
+        vis_pos = position_ids[:, :, start:end][:, :, idx]
+        pos = torch.cat([position_ids[:, :, :start], vis_pos, position_ids[:, :, end:]], dim=-1)
+    else:
+        pos = position_ids[:, :merged.size(1)]
+    return merged, pos, idx

@@ -75,3 +75,13 @@ def pool_close_enough(out, exp, meta):
         d = (out.view(torch.int16).int() - exp.view(torch.int16).int()).abs()
         return int(d.max()) <= 1
     return float((out - exp).abs().max()) <= 2e-6
+
+
+# ---- DyCoke stage-1 vectors (tests/golden/dyc_*.npz, made by make_golden_dycoke.py) --------------------------
+DYCOKE_GOLDEN = sorted(glob.glob(os.path.join(GOLDEN_DIR, "dyc_*.npz")))
+
+
+def load_dycoke_case(path):
+    z = np.load(path)
+    meta = json.loads(str(z["meta"]))
+    return meta, torch.from_numpy(z["x"]), torch.from_numpy(z["feat"]), torch.from_numpy(z["idx"])

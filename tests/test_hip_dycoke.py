@@ -1,0 +1,107 @@
+"""GPU parity tests of the DyCoke stage-1 kernels (sttm_amd.dycoke_merger.dycoke_ttm -> sttm_dycoke_ttm)."""
+import os
+
+import pytest
+import torch
+
+from tests._golden import DYCOKE_GOLDEN, load_dycoke_case
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _compare(out, idx, exp_f, exp_i, sims, P, k):
+    """Token ids must agree except where two similarities of a frame are within float rounding of each other (the device sums in
+    a different order than ATen); features are gathered rows, so they are exact for the ids that were chosen."""
+    assert out.shape == exp_f.shape and idx.shape == exp_i.shape and idx.dtype == torch.int64
+    if torch.equal(idx, exp_i):
+        return True
+    # allow swaps / cut differences only between tokens whose similarities differ by < 1e-6
+    bad = (idx != exp_i).nonzero().flatten().tolist()
+    for pos in bad:
+        a, b = int(idx[pos]), int(exp_i[pos])
+        assert a // P == b // P, "different frame at the same output row"
+        s = sims[a // P]
+        assert abs(float(s[a % P]) - float(s[b % P])) < 1e-6, (pos, a, b)
+    return False
+
+
+@pytest.mark.parametrize("path", DYCOKE_GOLDEN, ids=os.path.basename)
+def test_dycoke_golden_vectors(path):
+    from oracle import dycoke_oracle as D
+    from sttm_amd.dycoke_merger import dycoke_ttm
+    meta, x, feat, idx = load_dycoke_case(path)
+    out, oi = dycoke_ttm(x.to(DEV), meta["T"], meta["prune"])
+    out, oi = out.cpu(), oi.cpu()
+    P = meta["side"] ** 2
+    _, _, sims = D.dycoke_ttm(x, meta["T"], meta["prune"], return_sims=True)
+    _compare(out, oi, feat, idx, sims, P, int((1 - meta["prune"]) * P))
+    assert torch.equal(out, x[oi])                                        # rows are exact copies of the chosen tokens
+
+
+def test_dycoke_headline_size_against_oracle():
+    from oracle import dycoke_oracle as D
+    from sttm_amd.dycoke_merger import dycoke_ttm
+    from sttm_amd.synth import synth_video
+    T, C, P = 128, 1024, 196
+    exact = 0
+    for seed in range(3):
+        vid = synth_video(T, C, 14, 14, seed=seed)
+        g = torch.Generator().manual_seed(seed)
+        x = vid.permute(0, 2, 3, 1).reshape(T * P, C).contiguous() + 1e-3 * torch.randn(T * P, C, generator=g)
+        ef, ei, sims = D.dycoke_ttm(x, T, 0.7, return_sims=True)
+        out, oi = dycoke_ttm(x.to(DEV), T, 0.7)
+        exact += bool(_compare(out.cpu(), oi.cpu(), ef, ei, sims, P, int((1 - 0.7) * P)))
+        assert out.shape[0] == 64 * 196 + 64 * 58 - 31 * (196 - 58)       # 64 whole, 64 + 31 pruned frames
+    assert exact >= 2                                                     # index-exact on most clips
+
+
+def test_dycoke_interface_behaviour():
+    from sttm_amd.dycoke_merger import dycoke_ttm
+    x = torch.randn(4 * 9, 8, device=DEV)
+    with pytest.raises(RuntimeError):
+        dycoke_ttm(x, 4, 0.7)                                             # the reference stacks an empty list for T < 5
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        dycoke_ttm(torch.randn(6 * 9, 8), 6, 0.7)
+    with pytest.raises(NotImplementedError):
+        dycoke_ttm(torch.randn(6 * 9, 8, device=DEV).bfloat16(), 6, 0.7)
+    # ties (identical tokens everywhere): smaller token id first, and the output is still well formed
+    x = torch.ones(6 * 9, 8, device=DEV)
+    out, idx = dycoke_ttm(x, 6, 0.5)
+    k = int(0.5 * 9)
+    assert idx.tolist()[9:9 + k] == [9 + i for i in range(k)]
+
+
+def test_dycoke_stage1_pattern_runs_on_device():
+    transformers = pytest.importorskip("transformers")
+    from transformers import Qwen2Config
+    from transformers.models.qwen2.modeling_qwen2 import Qwen2Model
+    from oracle import dycoke_oracle as D
+    from sttm_amd import monkey_patch_interface as MPI
+    from sttm_amd import patch_hooks
+    torch.manual_seed(0)
+    C, T, P, start = 64, 6, 49, 5
+    cfg = Qwen2Config(vocab_size=64, hidden_size=C, intermediate_size=128, num_hidden_layers=3, num_attention_heads=4,
+                      num_key_value_heads=2, max_position_embeddings=4096, attn_implementation="sdpa")
+    model = Qwen2Model(cfg).eval().to(DEV)
+    hs = torch.randn(1, start + T * P + 9, C, device=DEV)
+    try:
+        MPI.replace_qwen2_by_sparse_attn("dycoke-stage1", sa_start_layer_idx=1, sa_prune_ratio=0.7)
+        model.image_token_start_index = torch.tensor(start)
+        model.image_token_length = torch.tensor(T * P)
+        model.num_frame = torch.tensor(T)
+        with torch.inference_mode():
+            out = model(inputs_embeds=hs, use_cache=False).last_hidden_state
+            pos = torch.arange(hs.shape[1], device=DEV).unsqueeze(0)
+            pe = model.rotary_emb(hs, pos)
+            h = model.layers[0](hs, attention_mask=None, position_embeddings=pe, position_ids=pos)
+            hm, pm, idx = patch_hooks.dycoke_merge(h.cpu(), pos.cpu(), start, T * P, T, D.dycoke_ttm, 0.7)
+            hm, pm = hm.to(DEV), pm.to(DEV)
+            pe = model.rotary_emb(hm, pm)
+            for layer in model.layers[1:]:
+                hm = layer(hm, attention_mask=None, position_embeddings=pe, position_ids=pm)
+            ref = model.norm(hm)
+        assert torch.equal(model.merged_token_1d_idx.cpu(), idx)
+        assert out.shape == ref.shape and torch.allclose(out, ref, atol=2e-5)
+    finally:
+        MPI.restore_qwen2()
