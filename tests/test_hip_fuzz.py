@@ -1,4 +1,6 @@
-"""Seeded fuzz of the HIP path against the oracle over random shapes / thresholds / variants (small sizes)."""
+"""Seeded fuzz of the HIP path against the oracle over random shapes / thresholds / variants (small sizes).
+STTM_FUZZ_N / STTM_FUZZ_SEED / STTM_FUZZ_TMAX widen or move the sweep for one-off runs (defaults: 200 cases, seed 1234)."""
+import os
 import random
 
 import pytest
@@ -12,7 +14,7 @@ def _cases(n, seed):
     out = []
     while len(out) < n:
         H, W = rng.randint(3, 30), rng.randint(3, 40)
-        T = rng.randint(1, 7)
+        T = rng.randint(1, int(os.environ.get("STTM_FUZZ_TMAX", "7")))
         C = rng.choice([8, 12, 16, 20, 32, 64, 100, 128, 256])
         dtype = rng.choice([torch.float32, torch.float32, torch.bfloat16, torch.float16])
         if dtype != torch.float32 and C % 2:
@@ -27,7 +29,7 @@ def _cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("case", _cases(200, 1234), ids=lambda c: "T%d_C%d_%dx%d_r%d_%s" % (c[0], c[1], c[2], c[3], c[5], c[10]))
+@pytest.mark.parametrize("case", _cases(int(os.environ.get("STTM_FUZZ_N", "200")), int(os.environ.get("STTM_FUZZ_SEED", "1234"))), ids=lambda c: "T%d_C%d_%dx%d_r%d_%s" % (c[0], c[1], c[2], c[3], c[5], c[10]))
 def test_fuzz_against_oracle(case):
     from oracle import sttm_oracle as O
     from sttm_amd import get_quadtree_features
