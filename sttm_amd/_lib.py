@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libsttm_hip.so")
 
 STTM_F32, STTM_BF16, STTM_F16 = 0, 1, 2
 ERR_ARG, ERR_UNSUPPORTED, ERR_LAUNCH, ERR_INDEX, ERR_PARITY, ERR_TIMEOUT = -1, -2, -3, -4, -5, -6
+ABI_VERSION = 3            # STTM_ABI_VERSION of include/sttm_hip.h this binding was written for
 CNT_NODES, CNT_CANDIDATES, CNT_EDGES, CNT_OUT, CNT_ITERS, CNT_OVERFLOW, CNT_LEAFNODES, CNT_SLOTS = 0, 1, 2, 3, 4, 5, 6, 8
 
 # every symbol include/sttm_hip.h declares, with its ctypes signature
@@ -56,7 +57,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.sttm_abi_version() != 3:
+    if lib.sttm_abi_version() != ABI_VERSION:
         raise RuntimeError("libsttm_hip.so ABI version mismatch")
     _lib = lib
     return lib

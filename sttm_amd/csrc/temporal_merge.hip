@@ -897,20 +897,42 @@ __global__ void __launch_bounds__(256) k_group_mean(TemporalArgs a) {
                 const void* s0 = (leaf && a.xrows) ? a.xrows : a.S;          // 1x1 nodes were not copied out of x
                 const bool divide = a.weighted_avg || n > 1;
                 const float den = round_to<T>(a.weighted_avg ? (float)patches : (float)n);
-                for (int c0 = lane * VEC; c0 < a.C; c0 += 64 * VEC) {
-                    Pack<T, VEC> acc = load_pack<T, VEC>(s0, (int64_t)origin * a.C + c0);
+                // U chunks of the row in flight per lane (wide rows would otherwise be a chain of load -> store round trips);
+                // per element the members are still added in ascending order, one rounding per add
+                constexpr int U = TypeInfo<T>::lowp ? 4 : 2;
+                for (int cb = lane * VEC; cb < a.C; cb += U * 64 * VEC) {
+                    Pack<T, VEC> acc[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int c0 = cb + u * 64 * VEC;
+                        if (c0 < a.C) acc[u] = load_pack<T, VEC>(s0, (int64_t)origin * a.C + c0); else acc[u].zero();
+                    }
                     for (int k = 1; k < n; ++k) {
                         const int mr = a.members[off + k];
                         const void* sm = (mr < 0 && a.xrows) ? a.xrows : a.S;
-                        const Pack<T, VEC> q = load_pack<T, VEC>(sm, (int64_t)(mr & 0x7fffffff) * a.C + c0);
+                        const int64_t mbase = (int64_t)(mr & 0x7fffffff) * a.C;
+                        Pack<T, VEC> q[U];
 #pragma unroll
-                        for (int e = 0; e < VEC; ++e) acc.set(e, acc.get(e) + q.get(e));
+                        for (int u = 0; u < U; ++u) {
+                            const int c0 = cb + u * 64 * VEC;
+                            if (c0 < a.C) q[u] = load_pack<T, VEC>(sm, mbase + c0); else q[u].zero();
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; ++u)
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) acc[u].set(e, acc[u].get(e) + q[u].get(e));
                     }
                     if (divide) {
 #pragma unroll
-                        for (int e = 0; e < VEC; ++e) acc.set(e, acc.get(e) / den);
+                        for (int u = 0; u < U; ++u)
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) acc[u].set(e, acc[u].get(e) / den);
                     }
-                    store_pack_stream<T, VEC>(a.feat_out, (int64_t)row * a.C + c0, acc);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int c0 = cb + u * 64 * VEC;
+                        if (c0 < a.C) store_pack_stream<T, VEC>(a.feat_out, (int64_t)row * a.C + c0, acc[u]);
+                    }
                 }
             }
             j0 += __popcll(m);

@@ -70,3 +70,14 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_abi_version_is_consistent_everywhere():
+    """include/sttm_hip.h, the built library, the ctypes binding and __graft_entry__.build() agree on the ABI version."""
+    import re
+    from sttm_amd import _lib
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "sttm_hip.h")).read()
+    v = int(re.search(r"#define STTM_ABI_VERSION (\d+)", header).group(1))
+    assert v == _lib.ABI_VERSION == _lib.load().sttm_abi_version()
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "__graft_entry__.py")).read()
+    assert "_lib.ABI_VERSION" in src
