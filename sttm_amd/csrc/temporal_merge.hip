@@ -475,6 +475,7 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nwave = nt >> 6;
     STTM_TICK(0);
+    if (a.dbg_ticks && blockIdx.x == a.dbg_wg && threadIdx.x == 0) a.dbg_ticks[12] = clock64();
     const Column col = make_column(a, r);
     const int slots = col.slots;
     // four arrays of `slots` ints each
@@ -732,10 +733,21 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
             if ((int)(old & 0xffffffull) == R - 1) publish_counts(a, (int)(old >> 24) + tot[2]);
         }
         STTM_TICK(11);
+        if (a.dbg_ticks && blockIdx.x == a.dbg_wg && threadIdx.x == 0) a.dbg_ticks[13] = clock64();
     }
 }
 
 constexpr size_t kColLdsLimit = 160 * 1024 - 1024;      // leave room for the static __shared__ scratch
+
+// Threads per column workgroup.  The phases are short and mostly per-thread bookkeeping (scans, address arithmetic): with
+// 16 waves on the CU's 4 SIMDs every instruction of a wave waits for three other waves to issue theirs.
+int col_threads(const TemporalArgs& a) {
+    static const int cap_env = [] { const char* e = getenv("STTM_LABEL_NT"); const int v = e ? atoi(e) : 0; return (v == 256 || v == 512 || v == 1024) ? v : 0; }();
+    const int cap = cap_env ? cap_env : kColThreads;
+    int nthreads = 256;
+    while (nthreads < cap && nthreads * 2 <= a.max_slots) nthreads *= 2;
+    return nthreads;
+}
 
 bool col_labels_use_gmem(const TemporalArgs& a) {
     return a.force_gmem || (size_t)18 * a.max_slots > kColLdsLimit;
@@ -743,8 +755,7 @@ bool col_labels_use_gmem(const TemporalArgs& a) {
 
 hipError_t launch_col_labels(const TemporalArgs& a, bool probe, hipStream_t stream) {
     const bool gmem = col_labels_use_gmem(a);
-    int nthreads = 256;
-    while (nthreads < kColThreads && nthreads * 2 <= a.max_slots) nthreads *= 2;
+    const int nthreads = col_threads(a);
     const size_t smem = gmem ? 0 : (size_t)18 * a.max_slots;
     if (probe) {
         if (!(a.temporal_thresh > 0.f && a.T > 1)) return hipSuccess;
@@ -765,8 +776,7 @@ hipError_t launch_labels_fused(const TemporalArgs& a, hipStream_t stream) {
     const bool gmem = col_labels_use_gmem(a);
     size_t smem = gmem ? 0 : (size_t)18 * a.max_slots;
     if (smem < sizeof(int) * (size_t)a.T) smem = sizeof(int) * (size_t)a.T;       // the rank phase keeps [T] prefixes there
-    int nthreads = 256;
-    while (nthreads < kColThreads && nthreads * 2 <= a.max_slots) nthreads *= 2;
+    const int nthreads = col_threads(a);
     if (gmem) hipLaunchKernelGGL((k_col_labels<COL_FUSED, true>), dim3(a.R), dim3(nthreads), smem, stream, a);
     else hipLaunchKernelGGL((k_col_labels<COL_FUSED, false>), dim3(a.R), dim3(nthreads), smem, stream, a);
     return hipGetLastError();

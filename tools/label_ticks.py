@@ -28,7 +28,9 @@ for it in range(12):
     assert rc == 0
     torch.cuda.synchronize()
     pos = off // 8
-    tk = ws.view(torch.int64)[pos:pos + 12].cpu().tolist()
+    tk = ws.view(torch.int64)[pos:pos + 14].cpu().tolist()
+    if it == 11: print('   shader clock during the kernel: %.0f MHz (clock64 delta / wall_clock64 delta)' % ((tk[13] - tk[12]) / ((tk[11] - tk[0]) / 100.0)))
+    tk = tk[:12]
     if it >= 2:
         d = [(b - a) / 100.0 for a, b in zip(tk[:-1], tk[1:])]
         acc = d if acc is None else [p + q for p, q in zip(acc, d)]
