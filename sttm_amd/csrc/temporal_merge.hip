@@ -468,7 +468,7 @@ enum { COL_PROBE = 0, COL_FINAL = 1, COL_FUSED = 2 };
 template <int MODE, bool GMEM>
 __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    __shared__ int flags[2];
+    __shared__ int flags[4];         // two (changed, not-idempotent) pairs, used by alternate iterations
     __shared__ int wsum[16];
     __shared__ unsigned long long wmask[16];
     const int r = blockIdx.x, R = a.R;
@@ -573,9 +573,11 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(TemporalArgs a) {
         int it = 0;
         bool overflow = false;
         while (true) {
-            column_iteration<GMEM>(rep, rep2, edges, E, slots, flags);
-            const int changed = flags[0], bad = flags[1];
-            col_sync<GMEM>();
+            // alternate flag pairs: iteration k+1 resets the OTHER pair, so no barrier is needed between reading this
+            // iteration's flags and starting the next one (the pair is reused two iterations, i.e. >= 3 barriers, later)
+            int* fl = flags + 2 * (it & 1);
+            column_iteration<GMEM>(rep, rep2, edges, E, slots, fl);
+            const int changed = fl[0], bad = fl[1];
             if (!bad) mask |= 1ull << it;
             ++it;
             if (!changed) break;                 // fixed point: stable => idempotent from here on
