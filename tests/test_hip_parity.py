@@ -93,6 +93,12 @@ ORACLE_CASES = [
     (5, 256, 14, 14, 16, torch.float32, 0.85, 0.55, 2, False),     # 2-level tree
     (5, 256, 14, 14, 17, torch.float32, 0.85, 0.55, 0, False),     # 4-level tree
     (1, 1024, 14, 14, 18, torch.float32, 0.85, 0.55, 1, False),    # single frame
+    (600, 64, 14, 14, 19, torch.float32, 0.85, 0.55, 1, False),    # long clip: 9600 slots per column -> global-scratch labels
+    (1024, 32, 14, 14, 20, torch.float32, 0.85, 0.55, 1, False),   # longest supported family (T * leaves per root cell <= 65536)
+    (300, 128, 27, 27, 21, torch.float32, 0.85, 0.60, 1, False),
+    (4, 64, 64, 64, 22, torch.float32, 0.85, 0.55, 2, False),      # big grid
+    (200, 96, 20, 36, 23, torch.float16, 0.85, 0.60, 0, False),    # 5-level tree, long clip, fp16
+    (32, 4096, 14, 14, 24, torch.float32, 0.85, 0.55, 1, False),   # widest fp32 row (1024 lanes)
 ]
 
 
