@@ -192,6 +192,19 @@ int64_t sttm_dycoke_out_rows(int T, int P, int k);
 int sttm_dycoke_ttm(const void* x, int T, int P, int C, int dtype, int k, void* workspace, size_t workspace_bytes,
                     void* out, int64_t* out_idx, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Octree baseline over the whole cubes of a clip: replaces octree_build (token_merging_utils/octree_utils.py:293-373).
+ *   x        [n_cubes * side, side, side, C] dense channels-last tokens (a cube = `side` consecutive frames of side x side)
+ *   feat_out [n_cubes * side^3, C] worst case; rows [0, N') are valid, ordered by the first-corner leaf index (:369-373)
+ *   count_out device int32: N'.   root_level indexes [2, ..., side] (halving with ceil, :312-316), negative from the end.
+ * The frames that do not fill a cube are the caller's job (the reference merges them per frame with the spatial
+ * quadtree, :375-378 -- sttm_quadtree_merge with temporal_thresh <= 0).
+ * Returns STTM_ERR_INDEX for a root level outside the list.  No host synchronisation.
+ * ------------------------------------------------------------------------------------------------ */
+size_t sttm_octree_workspace_bytes(int n_cubes, int side, int C, int dtype, int root_level);
+int sttm_octree_build(const void* x, int n_cubes, int side, int C, int dtype, float threshold, int root_level,
+                      void* workspace, size_t workspace_bytes, void* feat_out, int32_t* count_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

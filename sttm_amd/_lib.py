@@ -37,6 +37,8 @@ SIGNATURES = {
     "sttm_dycoke_workspace_bytes": (_sz, [_i, _i, _i]),
     "sttm_dycoke_out_rows": (ctypes.c_int64, [_i, _i, _i]),
     "sttm_dycoke_ttm": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp]),
+    "sttm_octree_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "sttm_octree_build": (_i, [_vp, _i, _i, _i, _i, ctypes.c_float, _i, _vp, _sz, _vp, _vp, _vp]),
     "sttm_resize_nearest": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
 }
 

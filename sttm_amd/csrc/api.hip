@@ -172,6 +172,57 @@ int pick_vec(int C, int dtype, const void* x, int64_t sT, int64_t sH, int64_t sW
     return 0;
 }
 
+// `sim_f32 >= thr_f32`  <=>  `sim >= lo` with lo = the midpoint below the fp32 threshold (exclusive when the tie would round
+// down to the predecessor, i.e. when the threshold's mantissa is odd); returned as lo * |lo| for the division-free test.
+double thr_lo_sq_of(float thr) {
+    const float pred = nextafterf(thr, -INFINITY);
+    double lo = 0.5 * ((double)pred + (double)thr);
+    uint32_t bits; memcpy(&bits, &thr, 4);
+    if (bits & 1u) lo = nextafter(lo, (double)INFINITY);
+    return lo * fabs(lo);
+}
+
+// Octree level list (octree_utils.py:312-316): [2, ..., side]; the pyramid runs from sizes[root_level] down to side.
+// Returns the number of pyramid levels (root first) or a negative error code.
+int octree_levels(int side, int root_level, int* sides /*[kOctMaxLevels]*/) {
+    if (side < 2) return STTM_ERR_ARG;
+    int list[32], n = 0;
+    int w = side;
+    list[n++] = w;
+    while (w != 2 && n < 32) { w = (w + 1) / 2; list[n++] = w; }        // fine -> coarse
+    if (w != 2) return STTM_ERR_ARG;
+    int idx = root_level < 0 ? n + root_level : root_level;             // index into the coarse -> fine list
+    if (idx < 0 || idx >= n) return STTM_ERR_INDEX;
+    const int L = n - idx;
+    if (L > sttm::kOctMaxLevels) return STTM_ERR_UNSUPPORTED;
+    for (int l = 0; l < L; ++l) sides[l] = list[n - 1 - idx - l];
+    return L;
+}
+
+struct OctPlan { int L; int side[sttm::kOctMaxLevels]; size_t off_feat[sttm::kOctMaxLevels], off_stop[sttm::kOctMaxLevels], off_mark, off_lvl, off_rows, off_scan, scan_bytes, total; };
+
+int octree_plan(int B, int side, int C, int dtype, int root_level, OctPlan* p) {
+    const int L = octree_levels(side, root_level, p->side);
+    if (L < 0) return L;
+    p->L = L;
+    size_t o = 0;
+    auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t eb = elem_bytes(dtype);
+    for (int l = 0; l < L - 1; ++l) {
+        const size_t cells = (size_t)B * p->side[l] * p->side[l] * p->side[l];
+        p->off_feat[l] = o; o = al(o + cells * C * eb);
+        p->off_stop[l] = o; o = al(o + cells);
+    }
+    const size_t leaves = (size_t)B * side * side * side;
+    p->off_mark = o; o = al(o + leaves * 4);
+    p->off_lvl = o; o = al(o + leaves);
+    p->off_rows = o; o = al(o + leaves * 4);
+    p->scan_bytes = sttm::octree_scan_bytes((int64_t)leaves);
+    p->off_scan = o; o = al(o + p->scan_bytes);
+    p->total = o;
+    return L;
+}
+
 // Group-mean workgroups per frame: enough 4-wave workgroups (T * split) to cover the chip several times over.
 int gm_split_for(int T) {
     static const int env = [] { const char* e = getenv("STTM_GM_SPLIT"); return e ? atoi(e) : 0; }();
@@ -338,12 +389,7 @@ int sttm_quadtree_merge_async(const void* x, int64_t stride_t, int64_t stride_c,
     {
         // `sim_f32 >= threshold_f32` <=> `sim >= lo`: lo = midpoint below the fp32 threshold (exclusive when the
         // tie would round down to the predecessor, i.e. when the threshold's mantissa is odd)
-        const float thr = threshold;
-        const float pred = nextafterf(thr, -INFINITY);
-        double lo = 0.5 * ((double)pred + (double)thr);
-        uint32_t bits; memcpy(&bits, &thr, 4);
-        if (bits & 1u) lo = nextafter(lo, (double)INFINITY);
-        sa.thr_lo_sq = lo * fabs(lo);
+        sa.thr_lo_sq = thr_lo_sq_of(threshold);
     }
     sa.sum_mode = weighted_avg ? 1 : 0;
     sa.n_head = n_head; sa.head_lanes = head_lanes;
@@ -494,6 +540,47 @@ int sttm_dycoke_ttm(const void* x, int T, int P, int C, int dtype, int k, void* 
     hipError_t e = sttm::launch_dycoke(reinterpret_cast<const float*>(x), T, P, C, k, sim, keep, reinterpret_cast<float*>(out), out_idx,
                                        reinterpret_cast<hipStream_t>(stream_));
     if (e != hipSuccess) return fail(STTM_ERR_LAUNCH, "dycoke kernels: %s", hipGetErrorString(e));
+    return STTM_OK;
+}
+
+size_t sttm_octree_workspace_bytes(int n_cubes, int side, int C, int dtype, int root_level) {
+    if (n_cubes < 1 || C < 1 || dtype < 0 || dtype > 2) { fail(STTM_ERR_ARG, "bad cubes/C/dtype"); return 0; }
+    OctPlan p;
+    const int L = octree_plan(n_cubes, side, C, dtype, root_level, &p);
+    if (L < 0) { fail(L, "octree levels"); return 0; }
+    return p.total;
+}
+
+int sttm_octree_build(const void* x, int n_cubes, int side, int C, int dtype, float threshold, int root_level,
+                      void* workspace, size_t workspace_bytes, void* feat_out, int32_t* count_out, void* stream_) {
+    if (!x || !workspace || !feat_out || !count_out || n_cubes < 1 || C < 1) return fail(STTM_ERR_ARG, "bad pointer or shape");
+    if (dtype < 0 || dtype > 2) return fail(STTM_ERR_ARG, "bad dtype");
+    if (dtype != STTM_F32 && (C & 1)) return fail(STTM_ERR_UNSUPPORTED, "16-bit inputs need an even channel count");
+    if ((int64_t)n_cubes * side * side * side >= (1ll << 31)) return fail(STTM_ERR_UNSUPPORTED, "more than 2^31 tokens");
+    OctPlan p;
+    const int L = octree_plan(n_cubes, side, C, dtype, root_level, &p);
+    if (L == STTM_ERR_INDEX) return fail(STTM_ERR_INDEX, "list index out of range (root_level %d for a cube side of %d)", root_level, side);
+    if (L < 0) return fail(L, "octree levels");
+    if (workspace_bytes < p.total) return fail(STTM_ERR_ARG, "workspace too small");
+    char* ws = reinterpret_cast<char*>(workspace);
+    sttm::OctArgs a;
+    memset(&a, 0, sizeof(a));
+    a.B = n_cubes; a.C = C; a.L = L;
+    for (int l = 0; l < L; ++l) a.side[l] = p.side[l];
+    for (int l = 0; l < L - 1; ++l) { a.feat[l] = ws + p.off_feat[l]; a.stop[l] = reinterpret_cast<uint8_t*>(ws + p.off_stop[l]); }
+    a.feat[L - 1] = x;
+    a.thr_lo_sq = thr_lo_sq_of(threshold);
+    a.mark = reinterpret_cast<int32_t*>(ws + p.off_mark);
+    a.level_of = reinterpret_cast<uint8_t*>(ws + p.off_lvl);
+    a.rows = reinterpret_cast<int32_t*>(ws + p.off_rows);
+    a.count_out = count_out;
+    a.out = feat_out;
+    const int eb = (int)elem_bytes(dtype);
+    int vec = 16 / eb;
+    const uintptr_t align = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(feat_out);
+    while (vec > (eb == 4 ? 1 : 2) && (C % vec || align % (vec * eb))) vec >>= 1;
+    hipError_t e = sttm::launch_octree(a, dtype, vec, ws + p.off_scan, p.scan_bytes, reinterpret_cast<hipStream_t>(stream_));
+    if (e != hipSuccess) return fail(STTM_ERR_LAUNCH, "octree kernels: %s", hipGetErrorString(e));
     return STTM_OK;
 }
 

@@ -85,6 +85,23 @@ bool col_labels_use_gmem(const TemporalArgs& a);
 
 hipError_t launch_pool2d(const void* x, void* out, int T, int H, int W, int C, int OH, int OW, int stride, int mode, int dtype,
                          hipStream_t stream);
+constexpr int kOctMaxLevels = 8;
+
+struct OctArgs {
+    int B, C, L;                         // cubes, channels, pyramid levels (0 = root level, L-1 = leaves)
+    int side[kOctMaxLevels];             // cells per axis
+    const void* feat[kOctMaxLevels];     // [B, side^3, C]; feat[L-1] = the input
+    uint8_t* stop[kOctMaxLevels];        // [B, side^3] for levels 0 .. L-2
+    double thr_lo_sq;
+    int32_t* mark;                       // [B * S^3] 1 = an emitted node starts at this leaf
+    uint8_t* level_of;                   // [B * S^3] level of that node
+    int32_t* rows;                       // [B * S^3] exclusive scan of mark
+    int32_t* count_out;
+    void* out;
+};
+
+size_t octree_scan_bytes(int64_t n);
+hipError_t launch_octree(OctArgs& a, int dtype, int vec, void* scan_tmp, size_t scan_bytes, hipStream_t stream);
 hipError_t launch_dycoke(const float* x, int T, int P, int C, int k, float* sim, int32_t* keep, float* out, int64_t* out_idx,
                          hipStream_t stream);
 hipError_t launch_label_edges(const int32_t* pairs, int L, int N, int32_t* rep_out, int32_t* rep2, int32_t* emin,

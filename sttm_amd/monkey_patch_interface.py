@@ -20,7 +20,6 @@ from .tome_interface import get_tome_features
 
 _UNIMPLEMENTED = {
     "quadtree-abl-pos": "position-embedding ablation (quadtree_attn_monkey_patch_for_abl_pos.py)",
-    "octree": "octree ablation (octree_utils.py)",
     "quadtree_vis": "visualisation variant",
     "dycoke": "DyCoke with stage-2 KV-cache pruning during decoding",
 }
@@ -82,6 +81,11 @@ def _qwen2_forward_with_merge(self, input_ids=None, attention_mask=None, positio
             elif self.sttm_pattern == "dycoke-stage1":
                 hidden_states, position_ids, idx = patch_hooks.dycoke_merge(
                     hidden_states, position_ids, start, length, T, type(self).sttm_dycoke_fn, self.sa_prune_ratio)
+            elif self.sttm_pattern == "octree":
+                hidden_states, position_ids = patch_hooks.octree_merge(
+                    hidden_states, position_ids, start, length, T, type(self).sttm_octree_fn, self.sa_tree_thresh,
+                    self.sa_tree_root_level)
+                idx = None                                            # the reference's octree hook keeps no token index
             else:
                 hidden_states, position_ids, idx = patch_hooks.tome_merge(
                     hidden_states, position_ids, start, length, T, type(self).sttm_tome_fn, self.sa_prune_ratio, self.sa_tome_ver)
@@ -200,6 +204,22 @@ def replace_qwen2_with_quadtree_attn(sa_start_layer_idx=0, sa_tree_thresh=0.90, 
     cls.forward = _qwen2_forward_with_merge
 
 
+def replace_qwen2_with_octree_attn(sa_start_layer_idx=0, sa_tree_thresh=0.90, sa_tree_root_level=0, **kwargs):
+    """octree_attn_monkey_patch.py:163-168."""
+    print("Replace Qwen2 attention path by OcTree token merging [sttm_amd / MI355X]")
+    cls = _qwen2_model_class()
+    cls.sttm_pattern = "octree"
+    cls.sa_start_layer_idx = sa_start_layer_idx
+    cls.sa_tree_thresh = sa_tree_thresh
+    cls.sa_tree_root_level = sa_tree_root_level
+    if not hasattr(cls, "sttm_octree_fn"):
+        from .octree_utils import get_octree_features
+        cls.sttm_octree_fn = staticmethod(get_octree_features)
+    if not hasattr(cls, "_sttm_original_forward"):
+        cls._sttm_original_forward = cls.forward
+    cls.forward = _qwen2_forward_with_merge
+
+
 def _install_dycoke(cls, forward, sa_start_layer_idx, sa_prune_ratio):
     cls.sttm_pattern = "dycoke-stage1"
     cls.sa_start_layer_idx = sa_start_layer_idx
@@ -309,6 +329,8 @@ def replace_qwen2_by_sparse_attn(pattern_name, **kwargs):
     elif pattern_name == "tome":
         replace_qwen2_with_tome_attn(**kwargs)
         replace_qwen2vl_with_tome_attn(**kwargs)
+    elif pattern_name == "octree":
+        replace_qwen2_with_octree_attn(**kwargs)
     elif pattern_name == "pyrd":
         replace_qwen2_with_pyrd_attn(**kwargs)
     elif pattern_name == "dycoke-stage1":

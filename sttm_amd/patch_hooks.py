@@ -106,3 +106,13 @@ def dycoke_merge(hidden_states, position_ids, start, length, T, ttm_fn, prune_ra
     else:
         pos = position_ids[:, :merged.size(1)]
     return merged, pos, idx
+
+
+def octree_merge(hidden_states, position_ids, start, length, T, octree_fn, threshold, root_level):
+    """Octree hook (octree_attn_monkey_patch.py:87-106): features only, position_ids truncated."""
+    sys_f, vis_f, inst_f = split_prompt(hidden_states, start, length)
+    H = int(math.sqrt(length // T))                                       # :96
+    video = _video_view(vis_f[0], T, H, H)
+    feat = octree_fn(video, threshold, root_level)
+    merged = torch.cat([sys_f, feat.unsqueeze(0), inst_f], dim=1)
+    return merged, position_ids[:, :merged.size(1)]

@@ -85,3 +85,14 @@ def load_dycoke_case(path):
     z = np.load(path)
     meta = json.loads(str(z["meta"]))
     return meta, torch.from_numpy(z["x"]), torch.from_numpy(z["feat"]), torch.from_numpy(z["idx"])
+
+
+# ---- octree vectors (tests/golden/oct_*.npz, made by make_golden_octree.py) ----------------------------------
+OCTREE_GOLDEN = sorted(glob.glob(os.path.join(GOLDEN_DIR, "oct_*.npz")))
+
+
+def load_octree_case(path):
+    z = np.load(path)
+    meta = json.loads(str(z["meta"]))
+    x = _t(z["x_thwc"], meta["dtype"]).permute(0, 3, 1, 2)          # [T, C, H, W] view of channels-last memory
+    return meta, x, _t(z["feat"], meta["dtype"])

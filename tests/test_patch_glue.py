@@ -57,7 +57,7 @@ def test_tome_hook():
 
 
 def test_installer_names_and_errors():
-    for name in ("quadtree-abl-pos", "octree", "quadtree_vis", "dycoke", "nonsense"):
+    for name in ("quadtree-abl-pos", "quadtree_vis", "dycoke", "nonsense"):
         with pytest.raises(NotImplementedError):
             MPI.replace_qwen2_by_sparse_attn(name)
 
