@@ -19,7 +19,6 @@ from .quadtree_interface import get_quadtree_features, get_quadtree_features_int
 from .tome_interface import get_tome_features
 
 _UNIMPLEMENTED = {
-    "quadtree-abl-pos": "position-embedding ablation (quadtree_attn_monkey_patch_for_abl_pos.py)",
     "quadtree_vis": "visualisation variant",
     "dycoke": "DyCoke with stage-2 KV-cache pruning during decoding",
 }
@@ -71,7 +70,13 @@ def _qwen2_forward_with_merge(self, input_ids=None, attention_mask=None, positio
         elif (prefilling and not merged and self.sttm_pattern != "pyrd" and i == self.sa_start_layer_idx
                 and getattr(self, "image_token_length", None) is not None):
             start, length, T = _item(self.image_token_start_index), _item(self.image_token_length), _item(self.num_frame)
-            if self.sttm_pattern == "quadtree":
+            if self.sttm_pattern == "quadtree-abl-pos":
+                head_dim = layer.self_attn.head_dim if self.sim_per_head else None
+                hidden_states, position_ids, position_embeddings, idx = patch_hooks.quadtree_merge_abl_pos(
+                    hidden_states, position_ids, position_embeddings, start, length, T, type(self).sttm_merge_fn,
+                    self.sa_tree_thresh, self.sa_tree_temporal_thresh, self.sa_tree_root_level, self.sa_tree_weighted_avg,
+                    self.pos_emb_ver, self.pos_emb_weighted_avg, self.rotary_emb, slow_ver=self.sttm_slow_ver, head_dim=head_dim)
+            elif self.sttm_pattern == "quadtree":
                 head_dim = layer.self_attn.head_dim if self.sim_per_head else None
                 hidden_states, position_ids, idx = patch_hooks.quadtree_merge_llava(
                     hidden_states, position_ids, start, length, T, type(self).sttm_merge_fn,
@@ -90,7 +95,8 @@ def _qwen2_forward_with_merge(self, input_ids=None, attention_mask=None, positio
                 hidden_states, position_ids, idx = patch_hooks.tome_merge(
                     hidden_states, position_ids, start, length, T, type(self).sttm_tome_fn, self.sa_prune_ratio, self.sa_tome_ver)
             self.merged_token_1d_idx = idx
-            position_embeddings = self.rotary_emb(hidden_states, position_ids)
+            if self.sttm_pattern != "quadtree-abl-pos":               # that hook decides its own position embeddings
+                position_embeddings = self.rotary_emb(hidden_states, position_ids)
             # batch-1 prefill without padding: the shorter sequence is plain causal
             mask_map = {k: None for k in mask_map}
             merged = True
@@ -202,6 +208,18 @@ def replace_qwen2_with_quadtree_attn(sa_start_layer_idx=0, sa_tree_thresh=0.90, 
     if not hasattr(cls, "_sttm_original_forward"):
         cls._sttm_original_forward = cls.forward
     cls.forward = _qwen2_forward_with_merge
+
+
+def replace_qwen2_with_quadtree_attn_for_abl_pos(sa_start_layer_idx=0, sa_tree_thresh=0.90, sa_tree_temporal_thresh=-1.0,
+                                                 sa_tree_root_level=0, sa_tree_weighted_avg=False, sttm_slow_ver=False,
+                                                 sim_per_head=False, pos_emb_ver=0, pos_emb_weighted_avg=False, **kwargs):
+    """quadtree_attn_monkey_patch_for_abl_pos.py:193-205."""
+    replace_qwen2_with_quadtree_attn(sa_start_layer_idx, sa_tree_thresh, sa_tree_temporal_thresh, sa_tree_root_level,
+                                     sa_tree_weighted_avg, sttm_slow_ver, sim_per_head)
+    cls = _qwen2_model_class()
+    cls.sttm_pattern = "quadtree-abl-pos"
+    cls.pos_emb_ver = pos_emb_ver
+    cls.pos_emb_weighted_avg = pos_emb_weighted_avg
 
 
 def replace_qwen2_with_octree_attn(sa_start_layer_idx=0, sa_tree_thresh=0.90, sa_tree_root_level=0, **kwargs):
@@ -329,6 +347,8 @@ def replace_qwen2_by_sparse_attn(pattern_name, **kwargs):
     elif pattern_name == "tome":
         replace_qwen2_with_tome_attn(**kwargs)
         replace_qwen2vl_with_tome_attn(**kwargs)
+    elif pattern_name == "quadtree-abl-pos":
+        replace_qwen2_with_quadtree_attn_for_abl_pos(**kwargs)
     elif pattern_name == "octree":
         replace_qwen2_with_octree_attn(**kwargs)
     elif pattern_name == "pyrd":

@@ -116,3 +116,40 @@ def octree_merge(hidden_states, position_ids, start, length, T, octree_fn, thres
     feat = octree_fn(video, threshold, root_level)
     merged = torch.cat([sys_f, feat.unsqueeze(0), inst_f], dim=1)
     return merged, position_ids[:, :merged.size(1)]
+
+
+def quadtree_merge_abl_pos(hidden_states, position_ids, position_embeddings, start, length, T, merge_fn, threshold,
+                           temporal_thresh, root_level, weighted_avg, pos_emb_ver, pos_emb_weighted_avg, rotary_fn,
+                           slow_ver=False, head_dim=None):
+    """Position-embedding ablation hook (quadtree_attn_monkey_patch_for_abl_pos.py:88-136).
+    pos_emb_ver 0: re-number the shorter sequence (the standard hook); 1: merge the RoPE (cos, sin) rows alongside the features
+    (`pos_embs=`); 2: keep every merged token's ORIGINAL position id (gather by the merged index).
+    rotary_fn(hidden_states, position_ids) -> (cos, sin).  Returns (hidden_states, position_ids, position_embeddings, idx)."""
+    sys_f, vis_f, inst_f = split_prompt(hidden_states, start, length)
+    end = start + length
+    H = W = int(math.sqrt(length // T))                                   # :97
+    video = _video_view(vis_f[0], T, H, W)
+    pos_video = None
+    if pos_emb_ver > 0:                                                   # :100-104
+        pos_video = tuple(_video_view(p[0, start:end], T, H, W) for p in position_embeddings)
+    res = merge_fn(video, threshold, temporal_thresh, root_level, weighted_avg, slow_ver=slow_ver, head_dim=head_dim,
+                   pos_embs=pos_video, pos_emb_weighted_avg=pos_emb_weighted_avg)
+    if pos_emb_ver > 0:
+        feat, _, tlbr, merged_pos = res
+    else:
+        feat, _, tlbr = res
+    idx = tlbr[:, 0] * (H * W) + tlbr[:, 1] * W + tlbr[:, 2]              # :113-114
+    merged = torch.cat([sys_f, feat.unsqueeze(0), inst_f], dim=1)
+    n = merged.size(1)
+    if pos_emb_ver == 0:                                                  # :120-123
+        position_ids = position_ids[:, :n]
+        position_embeddings = rotary_fn(merged, position_ids)
+    elif pos_emb_ver == 1:                                                # :124-128
+        position_embeddings = tuple(torch.cat([p[:, :start], mp.unsqueeze(0), p[:, end:]], dim=1)
+                                    for p, mp in zip(position_embeddings, merged_pos))
+        position_ids = position_ids[:, :n]
+    elif pos_emb_ver == 2:                                                # :129-135
+        vis_ids = position_ids[:, start:end][:, idx.long()]
+        position_ids = torch.cat([position_ids[:, :start], vis_ids, position_ids[:, end:]], dim=-1)
+        position_embeddings = rotary_fn(merged, position_ids)
+    return merged, position_ids, position_embeddings, idx

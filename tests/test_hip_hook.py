@@ -105,3 +105,27 @@ def test_patched_qwen2_forward_runs_on_device_and_matches_oracle_glue():
         MPI.restore_qwen2()
         if "sttm_merge_fn" in Qwen2Model.__dict__:
             del Qwen2Model.sttm_merge_fn
+
+
+@pytest.mark.parametrize("ver,weighted", [(1, False), (1, True), (2, False)])
+def test_abl_pos_hook_on_device_matches_oracle_glue(ver, weighted):
+    """quadtree-abl-pos hook (quadtree_attn_monkey_patch_for_abl_pos.py:88-136) through the HIP path vs the same glue with the oracle."""
+    from oracle import sttm_oracle as O
+    from sttm_amd import get_quadtree_features, patch_hooks
+    T, C, H = 6, 64, 14
+    hs, start, length = _prompt(T, C, H, H, torch.float32, seed=11)
+    S = hs.shape[1]
+    pos = torch.arange(S, device=hs.device).unsqueeze(0)
+    g = torch.Generator().manual_seed(5)
+    pe = tuple(torch.randn(1, S, 16, generator=g).to(hs.device) for _ in range(2))
+
+    def rot(h, p):
+        return tuple(torch.cos(p.float()).unsqueeze(-1).expand(-1, -1, 16) * (k + 1) for k in range(2))
+    a = patch_hooks.quadtree_merge_abl_pos(hs, pos, pe, start, length, T, get_quadtree_features, 0.85, 0.55, 1, False, ver,
+                                           weighted, rot)
+    b = patch_hooks.quadtree_merge_abl_pos(hs.cpu(), pos.cpu(), tuple(p.cpu() for p in pe), start, length, T,
+                                           O.get_quadtree_features, 0.85, 0.55, 1, False, ver, weighted, rot)
+    assert torch.equal(a[3].cpu(), b[3]) and torch.equal(a[1].cpu(), b[1])
+    assert float((a[0].cpu() - b[0]).abs().max()) <= 1e-5
+    for u, v in zip(a[2], b[2]):
+        assert float((u.cpu() - v).abs().max()) <= 1e-5

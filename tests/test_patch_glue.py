@@ -57,7 +57,7 @@ def test_tome_hook():
 
 
 def test_installer_names_and_errors():
-    for name in ("quadtree-abl-pos", "quadtree_vis", "dycoke", "nonsense"):
+    for name in ("quadtree_vis", "dycoke", "nonsense"):
         with pytest.raises(NotImplementedError):
             MPI.replace_qwen2_by_sparse_attn(name)
 
@@ -207,3 +207,55 @@ def test_pyrd_pattern_forward_matches_manual_layers():
         for name in ("sttm_resize_fn",):
             if name in Qwen2Model.__dict__:
                 delattr(Qwen2Model, name)
+
+
+
+@pytest.mark.parametrize("ver", [0, 1, 2])
+def test_abl_pos_pattern_forward_matches_manual_layers(ver):
+    """Position-embedding ablation (quadtree_attn_monkey_patch_for_abl_pos.py:88-136) with the oracle injected."""
+    transformers = pytest.importorskip("transformers")
+    from transformers import Qwen2Config
+    from transformers.models.qwen2.modeling_qwen2 import Qwen2Model
+    torch.manual_seed(0)
+    C, T = 32, 4
+    cfg = Qwen2Config(vocab_size=64, hidden_size=C, intermediate_size=64, num_hidden_layers=3, num_attention_heads=4,
+                      num_key_value_heads=2, max_position_embeddings=4096, attn_implementation="sdpa")
+    model = Qwen2Model(cfg).eval()
+    hs, start, length = _prompt(T=T, C=C)
+    try:
+        MPI.replace_qwen2_by_sparse_attn("quadtree-abl-pos", sa_start_layer_idx=1, sa_tree_thresh=0.85, sa_tree_temporal_thresh=0.55,
+                                         sa_tree_root_level=1, pos_emb_ver=ver, pos_emb_weighted_avg=False)
+        Qwen2Model.sttm_merge_fn = staticmethod(O.get_quadtree_features)
+        model.image_token_start_index = torch.tensor(start)
+        model.image_token_length = torch.tensor(length)
+        model.num_frame = torch.tensor(T)
+        with torch.inference_mode():
+            out = model(inputs_embeds=hs, use_cache=False).last_hidden_state
+            pos = torch.arange(hs.shape[1]).unsqueeze(0)
+            pe = model.rotary_emb(hs, pos)
+            h = model.layers[0](hs, attention_mask=None, position_embeddings=pe, position_ids=pos)
+            H = int(math.sqrt(length // T))
+            end = start + length
+            video = h[0, start:end].reshape(T, H, H, C).permute(0, 3, 1, 2)
+            if ver == 1:
+                pv = tuple(p[0, start:end].reshape(T, H, H, -1).permute(0, 3, 1, 2) for p in pe)
+                f, _, tl, mp = O.get_quadtree_features(video, 0.85, 0.55, 1, False, pos_embs=pv, pos_emb_weighted_avg=False)
+            else:
+                f, _, tl = O.get_quadtree_features(video, 0.85, 0.55, 1, False)
+            idx = (tl[:, 0] * H * H + tl[:, 1] * H + tl[:, 2]).long()
+            h = torch.cat([h[:, :start], f.unsqueeze(0), h[:, end:]], 1)
+            if ver == 0:
+                pos = pos[:, :h.shape[1]]; pe = model.rotary_emb(h, pos)
+            elif ver == 1:
+                pe = tuple(torch.cat([p[:, :start], m.unsqueeze(0), p[:, end:]], 1) for p, m in zip(pe, mp)); pos = pos[:, :h.shape[1]]
+            else:
+                pos = torch.cat([pos[:, :start], pos[:, start:end][:, idx], pos[:, end:]], -1); pe = model.rotary_emb(h, pos)
+            for layer in model.layers[1:]:
+                h = layer(h, attention_mask=None, position_embeddings=pe, position_ids=pos)
+            ref = model.norm(h)
+        assert out.shape == ref.shape and out.shape[1] < hs.shape[1]
+        assert torch.allclose(out, ref, atol=1e-5)
+    finally:
+        MPI.restore_qwen2()
+        if "sttm_merge_fn" in Qwen2Model.__dict__:
+            del Qwen2Model.sttm_merge_fn
