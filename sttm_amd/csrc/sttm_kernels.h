@@ -68,7 +68,7 @@ struct TemporalArgs {
     int32_t* grp_off;         // [T*H*W] by origin row
     int32_t* members;         // [T*H*W] origin rows (| leaf bit), grouped, ascending inside a group
     int32_t* counts;
-    int32_t* counts_host;     // optional host-mapped (pinned) mirror of counts, published by k_rank with slot 7 = seq
+    int32_t* counts_host;     // optional host-mapped (pinned) mirror of counts, published by the label kernel with slot 7 = seq
     int seq;
     // outputs
     void* feat_out;

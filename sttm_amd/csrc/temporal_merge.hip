@@ -359,7 +359,7 @@ __device__ __forceinline__ int box_area(uint32_t meta, int row, int HW, int W) {
 }
 
 constexpr int kColThreads = 1024;
-constexpr int kLeafBit = (int)0x80000000;     // members / row_info: the row is a 1x1 node (its feature lives in x, not S)
+constexpr int kLeafBit = (int)0x80000000;     // members: the row is a 1x1 node (its feature lives in x, not S)
 constexpr int kMaxProbeIters = 62;
 
 // Column arrays live in LDS (GMEM == false) or, for columns too large for the 160 KB LDS, in a per-column
@@ -777,7 +777,6 @@ bool labels_can_fuse(const TemporalArgs& a) { return a.R <= 128 && !a.no_fuse; }
 hipError_t launch_labels_fused(const TemporalArgs& a, hipStream_t stream) {
     const bool gmem = col_labels_use_gmem(a);
     size_t smem = gmem ? 0 : (size_t)18 * a.max_slots;
-    if (smem < sizeof(int) * (size_t)a.T) smem = sizeof(int) * (size_t)a.T;       // the rank phase keeps [T] prefixes there
     const int nthreads = col_threads(a);
     if (gmem) hipLaunchKernelGGL((k_col_labels<COL_FUSED, true>), dim3(a.R), dim3(nthreads), smem, stream, a);
     else hipLaunchKernelGGL((k_col_labels<COL_FUSED, false>), dim3(a.R), dim3(nthreads), smem, stream, a);
