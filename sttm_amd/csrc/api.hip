@@ -401,6 +401,10 @@ int sttm_quadtree_merge_async(const void* x, int64_t stride_t, int64_t stride_c,
         sa.pipeline = (np && np[0] == '1') ? 1 : 0;
         const char* dm = getenv("STTM_K1_ABLATE");      // only honoured by the profile leg: results are invalid
         sa.dbg_mode = (dm && g_prof_on) ? atoi(dm) : 0;
+        const char* kt = getenv("STTM_K1_TICKS");            // stamps land at the start of the column scratch (unused by K1)
+        const char* kw = getenv("STTM_K1_TICKS_WG");
+        sa.dbg_ticks = (kt && kt[0] == '1') ? reinterpret_cast<long long*>(b.colscratch) + 32 : nullptr;
+        sa.dbg_wg = kw ? atoi(kw) : 0;
     }
     sa.S = b.S; sa.meta = b.meta; sa.inrm = b.inrm; sa.rc_list = b.rc_list;
     sa.rc_stride = p.rc_stride;

@@ -17,6 +17,8 @@ struct SpatialArgs {
     int head_lanes;           // head_dim / vec: adjacent lanes that own one head (power of two <= 64)
     int pipeline;             // opt-in: persistent software-pipelined 3-level kernel (measured slower on MI355X)
     int dbg_mode;             // ablation (sttm_debug_spatial_ms only): 1 = stop after the statistics, 2 = loads + pooling only
+    long long* dbg_ticks;     // measurement tool only (STTM_K1_TICKS=1): wall_clock64 stamps of workgroup dbg_wg, else null
+    int dbg_wg;
     int leaves_in_x;          // x is a dense [T*H*W, C] matrix: 1x1 nodes are NOT copied to S (consumers read x)
     // outputs
     void* S;                  // [T*H*W, C] node features at their origin rows (input dtype)
