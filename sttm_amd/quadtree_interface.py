@@ -115,6 +115,9 @@ def _apply_side_tensor(v, ctx, root_level, sum_mode):
 _side_streams = {}
 
 
+_BATCH_TIMING = []          # measurement hook (tools/batch_streams.py): non-empty list -> timestamps after the enqueue loop
+
+
 def get_quadtree_features_batch(videos, threshold, temporal_thresh=-1.0, root_level=0, weighted_avg=False,
                                 slow_ver=False, head_dim=None, n_streams=3):
     """Extension (not in the reference, whose API is one video per call): merge a LIST of videos and return the list of
@@ -185,6 +188,9 @@ def get_quadtree_features_batch(videos, threshold, temporal_thresh=-1.0, root_le
                 hosts[j].data_ptr(), seq, st.cuda_stream)
             _lib.raise_for(rc)
             pend.append((feat, npatch, tlbr, seq, st, counts))
+        if _BATCH_TIMING:
+            import time as _t
+            _BATCH_TIMING.append(_t.perf_counter())
         out = []
         for j, (feat, npatch, tlbr, seq, st, counts) in enumerate(pend):
             if lib.sttm_wait_counts(hosts[j].data_ptr(), seq, 2_000_000) != 0:
