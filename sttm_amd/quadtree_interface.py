@@ -18,11 +18,14 @@ _ws_bytes_cache = {}    # (T, H, W, C, dtype, root_level) -> bytes
 _seq = [0]
 
 
-def _counts_host(device):
-    buf = _pinned_counts.get(device)
+def _counts_host(device, stream_handle):
+    """Pinned landing pad of the label kernel's counts: one per (device, stream), so callers on different streams
+    (e.g. two host threads) never share one."""
+    key = (device, stream_handle)
+    buf = _pinned_counts.get(key)
     if buf is None:
         buf = torch.zeros(_lib.CNT_SLOTS, dtype=torch.int32).pin_memory()
-        _pinned_counts[device] = buf
+        _pinned_counts[key] = buf
     return buf
 
 
@@ -73,7 +76,7 @@ def quadtree_merge_raw(x, threshold, temporal_thresh, root_level, weighted_avg, 
                 raise ValueError("feat_dest must be a contiguous, 16-byte aligned [rows, C] tensor of the input's dtype and device")
         npatch = torch.empty(N, dtype=torch.int32, device=dev)
         tlbr = torch.empty((N, 5), dtype=torch.int32, device=dev)
-        host = _counts_host(dev)
+        host = _counts_host(dev, stream.cuda_stream)
         _seq[0] = (_seq[0] % 0x3fffffff) + 1
         seq = _seq[0]
         rc = lib.sttm_quadtree_merge_async(

@@ -367,3 +367,34 @@ def test_tome_error_behaviour_matches_reference(case):
         assert (out is None) == case["returns_none"]
         if "n_out" in case:
             assert out[0].shape[0] == case["n_out"]
+
+
+def test_two_host_threads_on_their_own_streams():
+    """The drop-in call is safe from several host threads as long as each uses its own stream: scratch and the pinned count
+    buffer are per (device, stream)."""
+    import threading
+    from sttm_amd import get_quadtree_features
+    from sttm_amd.synth import synth_video
+    dev = _dev()
+    vids = [synth_video(16, 256, 14, 14, seed=40 + i).to(dev) for i in range(4)]
+    ref = [tuple(o.cpu() for o in get_quadtree_features(v, 0.85, 0.55, 1)) for v in vids]
+    torch.cuda.synchronize()
+    results, errors = {}, []
+
+    def work(k):
+        try:
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                for rep in range(25):
+                    for i in range(k, 4, 2):
+                        results[(k, i, rep)] = tuple(o.cpu() for o in get_quadtree_features(vids[i], 0.85, 0.55, 1))
+            st.synchronize()
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors
+    for (k, i, rep), out in results.items():
+        for a, b in zip(out, ref[i]):
+            assert torch.equal(a, b)
