@@ -160,6 +160,38 @@ def main():
         batched_value = videos / tb
         log(f"batched extension: {videos} videos in {tb:.4f} s = {batched_value:.1f} videos/s")
 
+    # ---- extension leg 2: the SAME one-video-per-call API from three host threads, each on its own stream (what a serving
+    #      process with several request threads does); skipped together with the batched leg ---------------------------------
+    threaded_value = None
+    if not args.no_batched:
+        import threading
+        NTH = 3
+        def worker(k, n_steps):
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                for s in range(n_steps):
+                    for v in range(k, V, NTH):
+                        get_quadtree_features(pool[(s * V + v) % P], thr, tthr, root)
+            st.synchronize()
+        def run_threads(n_steps):
+            th = [threading.Thread(target=worker, args=(k, n_steps)) for k in range(NTH)]
+            [t.start() for t in th]
+            [t.join() for t in th]
+        run_threads(1)
+        torch.cuda.synchronize()
+        barrier()
+        tt0 = time.perf_counter()
+        run_threads(K)
+        torch.cuda.synchronize()
+        barrier()
+        tt = time.perf_counter() - tt0
+        if dist is not None:
+            tmaxt = torch.tensor([tt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmaxt, op=dist.ReduceOp.MAX)
+            tt = float(tmaxt.item())
+        threaded_value = videos / tt
+        log(f"threaded drop-in extension: {videos} videos in {tt:.4f} s = {threaded_value:.1f} videos/s")
+
     # ---- roofline leg: the same K steps again with HIP events around every kernel of every call ----------
     lib.sttm_profile_enable(1)
     ms = (ctypes.c_float * 4)()
@@ -269,6 +301,9 @@ def main():
                                   "api": "get_quadtree_features_batch: the step's videos in one call, 3 side streams "
                                          "(not the reference's batch-1 API; identical outputs)"},
         }
+        out["threaded_dropin_extension"] = None if threaded_value is None else {
+            "value": round(threaded_value, 2), "unit": "videos/s",
+            "api": "get_quadtree_features, one video per call, from 3 host threads with one stream each (identical outputs)"}
         if cpu:
             out["index_match"] = cpu["index_exact_videos"] / max(1, cpu["videos_checked"])
         print(json.dumps(out), flush=True)
