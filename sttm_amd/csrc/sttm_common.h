@@ -36,10 +36,9 @@ struct f16_t { uint16_t x; };
 
 __device__ __forceinline__ float bf16_bits_to_float(uint32_t hi16) { return __uint_as_float(hi16 << 16); }
 __device__ __forceinline__ uint32_t float_to_bf16_bits(float f) {   // round to nearest even, NaN stays NaN
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
+    // gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32); the integer emulation cost ~6 VALU instructions per element,
+    // which made the 16-bit pooling / group-sum paths VALU-bound (1000+ instructions per thread in the spatial kernel)
+    return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)f);
 }
 __device__ __forceinline__ float f16_bits_to_float(uint32_t b) {
     return (float)__builtin_bit_cast(_Float16, (uint16_t)b);
@@ -59,6 +58,7 @@ template <int VEC> struct alignas(4 * VEC) Pack<float, VEC> {
     float v[VEC];
     __device__ __forceinline__ float get(int i) const { return v[i]; }
     __device__ __forceinline__ void set(int i, float f) { v[i] = f; }
+    __device__ __forceinline__ void set_pair(int i, float f0, float f1) { v[i] = f0; v[i + 1] = f1; }      // i even
     __device__ __forceinline__ void zero() {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) v[i] = 0.f;
@@ -78,14 +78,37 @@ template <typename T16, int VEC> struct alignas(2 * VEC) Pack16 {
         for (int i = 0; i < VEC / 2; ++i) w[i] = 0u;
     }
 };
+typedef float sttm_cvt_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 sttm_cvt_bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 sttm_cvt_f16x2 __attribute__((ext_vector_type(2)));
 template <int VEC> struct Pack<bf16_t, VEC> : Pack16<bf16_t, VEC> {
     __device__ __forceinline__ float get(int i) const { return bf16_bits_to_float(this->bits(i)); }
     __device__ __forceinline__ void set(int i, float f) { this->set_bits(i, float_to_bf16_bits(f)); }
+    // two adjacent channels (i even) with ONE v_cvt_pk_bf16_f32 and no merge of 16-bit halves
+    __device__ __forceinline__ void set_pair(int i, float f0, float f1) {
+        const sttm_cvt_f32x2 f = {f0, f1};
+        this->w[i >> 1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, sttm_cvt_bf16x2));
+    }
 };
 template <int VEC> struct Pack<f16_t, VEC> : Pack16<f16_t, VEC> {
     __device__ __forceinline__ float get(int i) const { return f16_bits_to_float(this->bits(i)); }
     __device__ __forceinline__ void set(int i, float f) { this->set_bits(i, float_to_f16_bits(f)); }
+    __device__ __forceinline__ void set_pair(int i, float f0, float f1) {
+        const sttm_cvt_f32x2 f = {f0, f1};
+        this->w[i >> 1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, sttm_cvt_f16x2));
+    }
 };
+// out[e] = fn(e) for every channel of a pack, written pairwise where the pack allows it
+template <typename T, int VEC, typename F>
+__device__ __forceinline__ void pack_fill(Pack<T, VEC>& out, F fn) {
+    if constexpr (VEC % 2 == 0) {
+#pragma unroll
+        for (int e = 0; e < VEC; e += 2) out.set_pair(e, fn(e), fn(e + 1));
+    } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) out.set(e, fn(e));
+    }
+}
 
 template <typename T, int VEC>
 __device__ __forceinline__ Pack<T, VEC> load_pack(const void* base, int64_t elem_off) {

@@ -929,15 +929,17 @@ __global__ void __launch_bounds__(256) k_group_mean(TemporalArgs a) {
                             if (c0 < a.C) q[u] = load_pack<T, VEC>(sm, mbase + c0); else q[u].zero();
                         }
 #pragma unroll
-                        for (int u = 0; u < U; ++u)
-#pragma unroll
-                            for (int e = 0; e < VEC; ++e) acc[u].set(e, acc[u].get(e) + q[u].get(e));
+                        for (int u = 0; u < U; ++u) {
+                            const Pack<T, VEC> prev = acc[u];
+                            pack_fill(acc[u], [&](int e) { return prev.get(e) + q[u].get(e); });
+                        }
                     }
                     if (divide) {
 #pragma unroll
-                        for (int u = 0; u < U; ++u)
-#pragma unroll
-                            for (int e = 0; e < VEC; ++e) acc[u].set(e, acc[u].get(e) / den);
+                        for (int u = 0; u < U; ++u) {
+                            const Pack<T, VEC> prev = acc[u];
+                            pack_fill(acc[u], [&](int e) { return prev.get(e) / den; });
+                        }
                     }
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
