@@ -83,3 +83,19 @@ def raise_for(code):
     if code == ERR_ARG:
         raise ValueError(msg)
     raise RuntimeError(f"libsttm_hip error {code}: {msg}")
+
+
+class BoundedCache(dict):
+    """Per-(device, stream) scratch cache with a bound: a caller that keeps creating streams must not pin one workspace
+    (≈100 MB for a 128-frame clip) per stream it ever used.  Oldest entries go first; the tensors are freed by the caching
+    allocator once the work queued on them has finished (they were allocated on that stream)."""
+    def __init__(self, limit=8):
+        super().__init__()
+        self.limit = int(os.environ.get("STTM_WS_CACHE", limit))
+
+    def __setitem__(self, key, value):
+        if key in self:
+            super().__delitem__(key)
+        super().__setitem__(key, value)
+        while len(self) > self.limit:
+            super().__delitem__(next(iter(self)))

@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 
-_ws_cache = {}
+_ws_cache = _lib.BoundedCache(8)      # (device, stream) -> scratch; bounded, see _lib.BoundedCache
 
 
 def dycoke_ttm(image_feature, num_frames, prune_ratio=0.7):

@@ -12,7 +12,7 @@ from . import _lib
 from .quadtree_interface import get_quadtree_features
 
 _DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
-_ws_cache = {}
+_ws_cache = _lib.BoundedCache(8)      # (device, stream) -> scratch; bounded, see _lib.BoundedCache
 
 
 def get_octree_features(_video_feature, threshold, root_level=0):

@@ -10,8 +10,8 @@ import torch
 from . import _lib
 
 _DTYPE_CODE = {torch.float32: _lib.STTM_F32, torch.bfloat16: _lib.STTM_BF16, torch.float16: _lib.STTM_F16}
-_pinned_counts = {}
-_ws_cache = {}          # device -> uint8 workspace tensor (grown on demand; safe to reuse: every call ends synchronised)
+_pinned_counts = _lib.BoundedCache(16)
+_ws_cache = _lib.BoundedCache(8)      # (device, stream) -> scratch; bounded, see _lib.BoundedCache
 _ws_bytes_cache = {}    # (T, H, W, C, dtype, root_level) -> bytes
 
 
@@ -174,6 +174,8 @@ def get_quadtree_features_batch(videos, threshold, temporal_thresh=-1.0, root_le
             if cached is None or cached[0].numel() < nbytes:
                 cached = (torch.empty(nbytes, dtype=torch.uint8, device=dev),
                           torch.empty(_lib.CNT_SLOTS, dtype=torch.int32, device=dev))
+                for t_ in cached:                      # allocated on the caller's stream, used on the side stream
+                    t_.record_stream(st)
                 _ws_cache[skey] = cached
             ws, counts = cached
             N = T * H * W
