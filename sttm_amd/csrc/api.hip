@@ -145,8 +145,32 @@ int make_plan(int T, int H, int W, int C, int dtype, int root_level, Plan* p) {
     return D;
 }
 
-int pick_vec(int C, int dtype, const void* x, int64_t sT, int64_t sH, int64_t sW, int* nt) {
+int pick_vec(int C, int dtype, const void* x, int64_t sT, int64_t sH, int64_t sW, int* nt, bool allow_wide16 = false) {
     const int eb = elem_bytes(dtype);
+    if (allow_wide16 && dtype != STTM_F32) {
+        // 32-byte packs for rows that need 5-8 waves with 16-byte packs (2048 < C <= 4096): four waves per root cell instead
+        // of seven halve the per-wave reduction butterflies.  Measured on T=128 bf16: C=3584 75.1 -> 65.0 us; no gain at
+        // C=8192 (16 -> 8 waves) and a loss at C=2048 (4 -> 2 waves), hence the window.  STTM_VEC16=8 / 16 force a width.
+        static const int want = [] { const char* e = getenv("STTM_VEC16"); return e ? atoi(e) : 0; }();
+        const int w8 = (C / 8 + 63) / 64;
+        const bool window = C % 8 == 0 && w8 > 4 && w8 <= 8;
+        if ((want == 16 || (want == 0 && window)) && C % 16 == 0 && reinterpret_cast<uintptr_t>(x) % 32 == 0 &&
+            (sT * eb) % 32 == 0 && (sH * eb) % 32 == 0 && (sW * eb) % 32 == 0 && C / 16 <= 512) {
+            *nt = ((C / 16 + 63) / 64) * 64;
+            return 16;
+        }
+    }
+    if (allow_wide16 && dtype == STTM_F32) {
+        // same idea for fp32 (32-byte packs); window mirrors the 16-bit one (5-8 waves with 16-byte packs: 1024 < C <= 2048)
+        static const int want32 = [] { const char* e = getenv("STTM_VEC32"); return e ? atoi(e) : 0; }();
+        const int w4 = (C / 4 + 63) / 64;
+        const bool window = C % 4 == 0 && w4 > 4 && w4 <= 8;
+        if ((want32 == 8 || (want32 == 0 && window)) && C % 8 == 0 && reinterpret_cast<uintptr_t>(x) % 32 == 0 &&
+            (sT * eb) % 32 == 0 && (sH * eb) % 32 == 0 && (sW * eb) % 32 == 0 && C / 8 <= 512) {
+            *nt = ((C / 8 + 63) / 64) * 64;
+            return 8;
+        }
+    }
     // 16 bytes per lane for every dtype.  For 16-bit inputs the 8-wide pack became affordable (128 VGPRs) once the
     // dot products moved to v_dot2c_f32_bf16/f16; measured on T=128, C=3584 bf16: spatial 107 -> 84 us,
     // group mean 69 -> 51 us, pairs 42 -> 31 us versus 4-wide packs (STTM_VEC16=4 restores them).
@@ -236,6 +260,8 @@ int gm_split_for(int T) {
 // 8-wide packs (two 16-byte loads in flight per lane; measured 23.7 -> 20.0 us for the group mean) even though the spatial
 // kernel keeps 4-wide packs for occupancy.  Per-head cosine keeps the spatial kernel's width (head lanes are defined on it).
 int row_vec(int C, int dtype, int spatial_vec, bool dense_x, const void* x, int head_dim) {
+    if (dtype != STTM_F32 && spatial_vec == 16) return 8;          // the row kernels have no 32-byte 16-bit packs
+    if (dtype == STTM_F32 && spatial_vec == 8) return (C % 8 == 0 && !(dense_x && reinterpret_cast<uintptr_t>(x) % 32)) ? 8 : 4;
     if (dtype != STTM_F32 || head_dim != 0 || spatial_vec != 4) return spatial_vec;
     if (C % 8 || C < 512) return spatial_vec;
     if (dense_x && reinterpret_cast<uintptr_t>(x) % 32) return spatial_vec;
@@ -364,7 +390,7 @@ int sttm_quadtree_merge_async(const void* x, int64_t stride_t, int64_t stride_c,
                             p.dims.h[l], p.dims.w[l]);
     }
     int nt = 0;
-    const int vec = pick_vec(C, dtype, x, stride_t, stride_h, stride_w, &nt);
+    const int vec = pick_vec(C, dtype, x, stride_t, stride_h, stride_w, &nt, head_dim == 0);
     if (!vec) return fail(STTM_ERR_UNSUPPORTED, "C=%d with this alignment does not fit one workgroup (need C/vec <= 1024 lanes)", C);
 
     if (p.max_slots > 65536)

@@ -99,6 +99,10 @@ ORACLE_CASES = [
     (4, 64, 64, 64, 22, torch.float32, 0.85, 0.55, 2, False),      # big grid
     (200, 96, 20, 36, 23, torch.float16, 0.85, 0.60, 0, False),    # 5-level tree, long clip, fp16
     (32, 4096, 14, 14, 24, torch.float32, 0.85, 0.55, 1, False),   # widest fp32 row (1024 lanes)
+    (6, 2048, 14, 14, 25, torch.float32, 0.85, 0.55, 1, False),    # fp32 rows of 5-8 waves: 32-byte packs in the spatial kernel
+    (6, 1536, 14, 14, 26, torch.float32, 0.85, 0.55, 1, True),
+    (6, 2560, 14, 14, 27, torch.float16, 0.85, 0.55, 1, False),    # 16-bit rows of 5-8 waves: 32-byte packs
+    (6, 4096, 20, 36, 28, torch.bfloat16, 0.85, 0.60, 1, False),   # ... with a 4-level tree
 ]
 
 
