@@ -402,3 +402,19 @@ def test_two_host_threads_on_their_own_streams():
     for (k, i, rep), out in results.items():
         for a, b in zip(out, ref[i]):
             assert torch.equal(a, b)
+
+
+def test_c_abi_demo_runs_without_python_or_torch():
+    """examples/c_abi_demo.cpp drives the library from plain C++ (hipMalloc + the C ABI): the boundary carries no torch types."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "c_abi_demo")
+    if not os.path.exists(exe):
+        if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+            pytest.skip("no hipcc to build the demo")
+        subprocess.run(["bash", os.path.join(root, "examples", "build_demo.sh")], check=True, timeout=600)
+    r = subprocess.run([exe, "32", "256"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "sum of num_patches" in r.stdout
