@@ -133,6 +133,11 @@ __global__ void __launch_bounds__(256) k_pairs(TemporalArgs a) {
         const unsigned b = (unsigned)L[1 + i];
         return frame * HW + (int)(b >> 24) * a.W + (int)((b >> 16) & 255);
     };
+    // column-local slot of a list entry, straight from its box (no division: row_to_slot would divide by H*W and W)
+    auto slot_of = [&](const int* L, int i, int frame) {
+        const unsigned b = (unsigned)L[1 + i];
+        return frame * col.A + ((int)(b >> 24) - col.Y1) * col.aw + ((int)((b >> 16) & 255) - col.X1);
+    };
     auto src_of = [&](const int* L, int i) -> const void* {      // 1x1 nodes were not copied out of x
         const unsigned b = (unsigned)L[1 + i];
         const bool leaf = ((b >> 8) & 255) - (b >> 24) == 1 && (b & 255) - ((b >> 16) & 255) == 1;
@@ -162,7 +167,7 @@ __global__ void __launch_bounds__(256) k_pairs(TemporalArgs a) {
             acc = wave_sum(acc);
             if (lane == 0 && acc / (float)a.n_head >= a.temporal_thresh) {
                 const int e = atomicAdd(&nkept, 1);
-                my_edges[e] = (int)(((unsigned)row_to_slot(a, col, rowA) << 16) | (unsigned)row_to_slot(a, col, rowB));
+                my_edges[e] = (int)(((unsigned)slot_of(LA, k0 >> 16, t) << 16) | (unsigned)slot_of(LB, k0 & 0xffff, t + 1));
             }
         }
     } else
@@ -197,7 +202,6 @@ __global__ void __launch_bounds__(256) k_pairs(TemporalArgs a) {
         d1 = wave_sum(d1);
         if (a.inline_norms) { na0 = wave_sum(na0); nb0 = wave_sum(nb0); na1 = wave_sum(na1); nb1 = wave_sum(nb1); }
         if (lane < 2 && (lane == 0 || two)) {
-            const int rowA = lane ? rowA1 : rowA0, rowB = lane ? rowB1 : rowB0;
             const float dot = lane ? d1 : d0;
             // x / (|x| + 1e-8) on both sides (quadtree_temporal_merger.py:62-63); the spatial kernel stored
             // 1 / (|x| + 1e-8) in double
@@ -207,7 +211,8 @@ __global__ void __launch_bounds__(256) k_pairs(TemporalArgs a) {
             if (sim >= a.temporal_thresh) {
                 const int e = atomicAdd(&nkept, 1);
                 if (a.edge_sim) a.edge_sim[cidx * cap + e] = sim;
-                my_edges[e] = (int)(((unsigned)row_to_slot(a, col, rowA) << 16) | (unsigned)row_to_slot(a, col, rowB));
+                const int kk = lane ? k1 : k0;
+                my_edges[e] = (int)(((unsigned)slot_of(LA, kk >> 16, t) << 16) | (unsigned)slot_of(LB, kk & 0xffff, t + 1));
             }
         }
     }
