@@ -469,6 +469,10 @@ int sttm_quadtree_merge_async(const void* x, int64_t stride_t, int64_t stride_c,
         const char* tw = getenv("STTM_LABEL_TICKS_WG");
         ta.dbg_wg = tw ? atoi(tw) : 0;
         ta.dbg_ticks = (tk && tk[0] == '1') ? reinterpret_cast<long long*>(b.colscratch) : nullptr;
+        const char* k2 = getenv("STTM_K2_TICKS");
+        const char* k2w = getenv("STTM_K2_TICKS_WG");
+        ta.dbg_ticks_k2 = (k2 && k2[0] == '1') ? reinterpret_cast<long long*>(b.colscratch) + 64 : nullptr;
+        ta.dbg_wg_k2 = k2w ? atoi(k2w) : 0;
     } ta.colscratch = b.colscratch;
     ta.gm_split = gm_split_for(T); ta.grp_np = b.grp_np; ta.grp_cnt = b.grp_cnt; ta.grp_off = b.grp_off; ta.members = b.members;
     ta.counts = counts;

@@ -63,6 +63,8 @@ struct TemporalArgs {
     int no_fuse;              // debug/test: use the three-kernel label path
     int dbg_wg;               // debug: which workgroup stamps
     long long* dbg_ticks;     // debug: wall_clock64 stamps of workgroup 0 at phase boundaries (null = off)
+    long long* dbg_ticks_k2;  // debug (STTM_K2_TICKS=1): stamps of pair-kernel workgroup dbg_wg_k2
+    int dbg_wg_k2;
     int32_t* colscratch;      // [5*T*H*W] label arrays of columns that do not fit LDS
     int gm_split;             // group-mean workgroups per frame
     int32_t* grp_np;          // [T*H*W] by origin row: patches covered by the group

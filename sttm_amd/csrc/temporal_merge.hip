@@ -87,6 +87,9 @@ __global__ void __launch_bounds__(256) k_pairs(TemporalArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     int* cand = reinterpret_cast<int*>(smem_raw);     // [cap] packed (ia << 16 | ib)
     __shared__ int ncand, nkept;
+#define STTM_K2_TICK(n) do { if (a.dbg_ticks_k2 && blockIdx.x == a.dbg_wg_k2 && threadIdx.x == 0) a.dbg_ticks_k2[n] = wall_clock64(); } while (0)
+    STTM_K2_TICK(0);
+    if (a.dbg_ticks_k2 && blockIdx.x == 0 && threadIdx.x == 0) a.dbg_ticks_k2[8] = wall_clock64();
     const int R = a.R;
     int t, r;
     if (a.pairs_seg > 0) {
@@ -107,27 +110,50 @@ __global__ void __launch_bounds__(256) k_pairs(TemporalArgs a) {
     const int HW = a.H * a.W;
     const int* LA = a.rc_list + (int64_t)(t * R + r) * a.rc_stride;
     const int* LB = a.rc_list + (int64_t)((t + 1) * R + r) * a.rc_stride;
-    const int nA = LA[0], nB = LB[0];
     const int cap = a.ecap;
     const Column col = make_column(a, r);
     const int64_t cidx = (int64_t)r * (a.T - 1) + t;          // column-major: a column's lists are contiguous
     int32_t* my_edges = a.edges + cidx * cap;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
+    // ONE round trip for the counts and the node boxes of both cells: every list entry is fetched speculatively (entries past
+    // the count are stale but inside the row) and parked in LDS for the box tests
+    int* listA = cand + cap;                              // [rc_stride]
+    int* listB = listA + a.rc_stride;                     // [rc_stride]
+    for (int i = tid; i < a.rc_stride; i += blockDim.x) { listA[i] = LA[i]; listB[i] = LB[i]; }
     if (tid == 0) { ncand = 0; nkept = 0; }
     __syncthreads();
-    for (int p = tid; p < nA * nB; p += blockDim.x) {
-        const int ia = p / nB, ib = p - ia * nB;
-        const unsigned ba = (unsigned)LA[1 + ia], bb = (unsigned)LB[1 + ib];
-        const int ay1 = ba >> 24, ax1 = (ba >> 16) & 255, ay2 = (ba >> 8) & 255, ax2 = ba & 255;
+    const int nA = listA[0], nB = listB[0];
+    // box tests on a (ia, ib) grid whose width is the power of two >= nB: no integer division per test
+    int lg = 0;
+    while ((1 << lg) < nB) ++lg;
+    const int ib = tid & ((1 << lg) - 1), ia0 = tid >> lg, ia_step = blockDim.x >> lg;
+    if (ib < nB && ia_step > 0) {
+        const unsigned bb = (unsigned)listB[1 + ib];
         const int by1 = bb >> 24, bx1 = (bb >> 16) & 255, by2 = (bb >> 8) & 255, bx2 = bb & 255;
-        const bool a_has_b = ay1 <= by1 && ax1 <= bx1 && ay2 >= by2 && ax2 >= bx2;
-        const bool b_has_a = ay1 >= by1 && ax1 >= bx1 && ay2 <= by2 && ax2 <= bx2;
-        if (a_has_b || b_has_a) {
-            const int pos = atomicAdd(&ncand, 1);
-            if (pos < cap) cand[pos] = (ia << 16) | ib;
+        for (int ia = ia0; ia < nA; ia += ia_step) {
+            const unsigned ba = (unsigned)listA[1 + ia];
+            const int ay1 = ba >> 24, ax1 = (ba >> 16) & 255, ay2 = (ba >> 8) & 255, ax2 = ba & 255;
+            const bool a_has_b = ay1 <= by1 && ax1 <= bx1 && ay2 >= by2 && ax2 >= bx2;
+            const bool b_has_a = ay1 >= by1 && ax1 >= bx1 && ay2 <= by2 && ax2 <= bx2;
+            if (a_has_b || b_has_a) {
+                const int pos = atomicAdd(&ncand, 1);
+                if (pos < cap) cand[pos] = (ia << 16) | ib;
+            }
+        }
+    } else if (ia_step == 0) {                            // more nodes in the cell than threads (block-size override): plain loop
+        for (int p = tid; p < nA * nB; p += blockDim.x) {
+            const int ia = p / nB, jb = p - ia * nB;
+            const unsigned ba = (unsigned)listA[1 + ia], bb = (unsigned)listB[1 + jb];
+            const int ay1 = ba >> 24, ax1 = (ba >> 16) & 255, ay2 = (ba >> 8) & 255, ax2 = ba & 255;
+            const int by1 = bb >> 24, bx1 = (bb >> 16) & 255, by2 = (bb >> 8) & 255, bx2 = bb & 255;
+            if ((ay1 <= by1 && ax1 <= bx1 && ay2 >= by2 && ax2 >= bx2) || (ay1 >= by1 && ax1 >= bx1 && ay2 <= by2 && ax2 <= bx2)) {
+                const int pos = atomicAdd(&ncand, 1);
+                if (pos < cap) cand[pos] = (ia << 16) | jb;
+            }
         }
     }
     __syncthreads();
+    STTM_K2_TICK(1);
     const int nc = ncand < cap ? ncand : cap;
     auto row_of = [&](const int* L, int i, int frame) {
         const unsigned b = (unsigned)L[1 + i];
@@ -148,8 +174,8 @@ __global__ void __launch_bounds__(256) k_pairs(TemporalArgs a) {
         const int G = a.head_lanes;
         for (int c = wave; c < nc; c += nwave) {
             const int k0 = cand[c];
-            const int rowA = row_of(LA, k0 >> 16, t), rowB = row_of(LB, k0 & 0xffff, t + 1);
-            const void* sA = src_of(LA, k0 >> 16); const void* sB = src_of(LB, k0 & 0xffff);
+            const int rowA = row_of(listA, k0 >> 16, t), rowB = row_of(listB, k0 & 0xffff, t + 1);
+            const void* sA = src_of(listA, k0 >> 16); const void* sB = src_of(listB, k0 & 0xffff);
             float acc = 0.f;
             for (int base = 0; base < a.C; base += 64 * VEC) {
                 const int c0 = base + lane * VEC;
@@ -167,7 +193,7 @@ __global__ void __launch_bounds__(256) k_pairs(TemporalArgs a) {
             acc = wave_sum(acc);
             if (lane == 0 && acc / (float)a.n_head >= a.temporal_thresh) {
                 const int e = atomicAdd(&nkept, 1);
-                my_edges[e] = (int)(((unsigned)slot_of(LA, k0 >> 16, t) << 16) | (unsigned)slot_of(LB, k0 & 0xffff, t + 1));
+                my_edges[e] = (int)(((unsigned)slot_of(listA, k0 >> 16, t) << 16) | (unsigned)slot_of(listB, k0 & 0xffff, t + 1));
             }
         }
     } else
@@ -175,10 +201,10 @@ __global__ void __launch_bounds__(256) k_pairs(TemporalArgs a) {
         const int c2 = c + nwave;
         const bool two = c2 < nc;
         const int k0 = cand[c], k1 = two ? cand[c2] : k0;
-        const int rowA0 = row_of(LA, k0 >> 16, t), rowB0 = row_of(LB, k0 & 0xffff, t + 1);
-        const int rowA1 = row_of(LA, k1 >> 16, t), rowB1 = row_of(LB, k1 & 0xffff, t + 1);
-        const void* sA0 = src_of(LA, k0 >> 16); const void* sB0 = src_of(LB, k0 & 0xffff);
-        const void* sA1 = src_of(LA, k1 >> 16); const void* sB1 = src_of(LB, k1 & 0xffff);
+        const int rowA0 = row_of(listA, k0 >> 16, t), rowB0 = row_of(listB, k0 & 0xffff, t + 1);
+        const int rowA1 = row_of(listA, k1 >> 16, t), rowB1 = row_of(listB, k1 & 0xffff, t + 1);
+        const void* sA0 = src_of(listA, k0 >> 16); const void* sB0 = src_of(listB, k0 & 0xffff);
+        const void* sA1 = src_of(listA, k1 >> 16); const void* sB1 = src_of(listB, k1 & 0xffff);
         // the two lanes that finish the cosines fetch their inverse norms now, under the row loads
         double pre_ia = 0.0, pre_ib = 0.0;
         if (lane < 2 && !a.inline_norms) {
@@ -212,16 +238,20 @@ __global__ void __launch_bounds__(256) k_pairs(TemporalArgs a) {
                 const int e = atomicAdd(&nkept, 1);
                 if (a.edge_sim) a.edge_sim[cidx * cap + e] = sim;
                 const int kk = lane ? k1 : k0;
-                my_edges[e] = (int)(((unsigned)slot_of(LA, kk >> 16, t) << 16) | (unsigned)slot_of(LB, kk & 0xffff, t + 1));
+                my_edges[e] = (int)(((unsigned)slot_of(listA, kk >> 16, t) << 16) | (unsigned)slot_of(listB, kk & 0xffff, t + 1));
             }
         }
     }
     __syncthreads();
+    STTM_K2_TICK(2);
     for (int e = nkept + tid; e < cap; e += blockDim.x) my_edges[e] = -1;      // unused entries: the reader scans all `cap`
     if (tid == 0) {
         a.edge_cnt[cidx] = nkept;
         a.cand_cnt[cidx] = ncand;
     }
+    STTM_K2_TICK(3);
+    if (a.dbg_ticks_k2 && blockIdx.x == a.dbg_wg_k2 && threadIdx.x == 0) a.dbg_ticks_k2[4] = ncand;
+#undef STTM_K2_TICK
 }
 
 hipError_t launch_pairs(const TemporalArgs& a, hipStream_t stream) {
@@ -231,7 +261,7 @@ hipError_t launch_pairs(const TemporalArgs& a, hipStream_t stream) {
         const int segs = (a.T - 1 + a.pairs_seg - 1) / a.pairs_seg;
         grid = 8 * ((a.R * segs + 7) / 8) * a.pairs_seg;
     }
-    const size_t smem = sizeof(int) * (size_t)a.ecap;
+    const size_t smem = sizeof(int) * ((size_t)a.ecap + 2 * (size_t)a.rc_stride);      // candidates + the two node lists
     static const int nt_env = [] { const char* e = getenv("STTM_PAIRS_NT"); const int v = e ? atoi(e) : 0; return (v == 64 || v == 128 || v == 256) ? v : 0; }();
     const int nt = nt_env ? nt_env : 256;
 #define STTM_LAUNCH_PAIRS(TT, VV) hipLaunchKernelGGL((k_pairs<TT, VV>), dim3(grid), dim3(nt), smem, stream, a)
