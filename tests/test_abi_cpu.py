@@ -81,3 +81,42 @@ def test_abi_version_is_consistent_everywhere():
     assert v == _lib.ABI_VERSION == _lib.load().sttm_abi_version()
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "__graft_entry__.py")).read()
     assert "_lib.ABI_VERSION" in src
+
+
+def test_everything_around_the_path_refuses_cpu_tensors():
+    """No CPU fallback anywhere in the product package: the producers / baselines around the path fail loudly too."""
+    import torch
+    from sttm_amd.dycoke_merger import dycoke_ttm
+    from sttm_amd.octree_utils import get_octree_features
+    from sttm_amd.upstream import get_2dPool, resize_nearest
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        get_2dPool(torch.zeros(2, 81, 8), stride=2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        resize_nearest(torch.zeros(2, 81, 8), 9, 9, (5, 5))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        dycoke_ttm(torch.zeros(6 * 9, 8), 6, 0.7)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        get_octree_features(torch.zeros(14, 8, 14, 14), 0.85, 0)
+    assert get_2dPool(torch.zeros(2, 81, 8), stride=1).shape == (2, 81, 8)          # the reference's identity case needs no device
+
+
+def test_bounded_cache_evicts_oldest():
+    from sttm_amd._lib import BoundedCache
+    c = BoundedCache(3)
+    for k in range(5):
+        c[k] = k * 10
+    assert list(c.keys()) == [2, 3, 4]
+    c[2] = 99                        # re-inserting refreshes the entry
+    c[7] = 70
+    assert list(c.keys()) == [4, 2, 7] and c[2] == 99
+
+
+def test_host_side_size_functions_of_the_baselines():
+    lib = _lib.load()
+    # pooled side lengths (llava_arch.py:185-192): bilinear rounds up, average / max round down
+    assert lib.sttm_pool2d_out_side(27, 2, 2) == 14 and lib.sttm_pool2d_out_side(27, 2, 0) == 13 and lib.sttm_pool2d_out_side(27, 1, 1) == 27
+    # DyCoke output rows: T = 128, P = 196, k = 58 -> 33 whole frames + 95 pruned ones
+    assert lib.sttm_dycoke_out_rows(128, 196, 58) == 33 * 196 + 95 * 58
+    assert lib.sttm_dycoke_out_rows(5, 49, 24) == 2 * 49 + 3 * 24
+    # octree: root level outside [2, ..., side] -> no workspace (the wrapper raises IndexError)
+    assert lib.sttm_octree_workspace_bytes(1, 14, 32, 0, 9) == 0 and lib.sttm_octree_workspace_bytes(1, 14, 32, 0, 0) > 0
