@@ -28,7 +28,7 @@ struct SpatialArgs {
     int rc_stride;
     int32_t* counts;          // STTM_CNT_* slots (zeroed here, filled by the later kernels)
     int32_t* frame_cnt;       // [T] zeroed here for the label kernels
-    int32_t* bar;             // [2] zeroed here (grid-barrier counters of the fused label kernel)
+    int32_t* bar;             // [4] zeroed here: [0] grid-barrier counter of the fused label kernel, [2..3] the 64-bit arrival/total word
 };
 hipError_t launch_spatial(const SpatialArgs& a, int dtype, int vec, int nt, hipStream_t stream);
 hipError_t launch_node_apply(const SpatialArgs& a, int dtype, int vec, int nt, hipStream_t stream);
