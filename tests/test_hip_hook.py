@@ -129,3 +129,61 @@ def test_abl_pos_hook_on_device_matches_oracle_glue(ver, weighted):
     assert float((a[0].cpu() - b[0]).abs().max()) <= 1e-5
     for u, v in zip(a[2], b[2]):
         assert float((u.cpu() - v).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("pattern", ["quadtree", "dycoke-stage1", "tome"])
+def test_patched_qwen2vl_text_model_runs_on_device(pattern):
+    """Qwen2-VL text model (3-D mRoPE ids gathered by the merged-token index) through the HIP path, against the same forward done
+    by hand with the CPU oracles doing the merge."""
+    pytest.importorskip("transformers")
+    try:
+        from transformers.models.qwen2_vl.configuration_qwen2_vl import Qwen2VLTextConfig
+        from transformers.models.qwen2_vl.modeling_qwen2_vl import Qwen2VLTextModel
+    except Exception:  # noqa: BLE001
+        pytest.skip("this transformers has no Qwen2VLTextModel")
+    from oracle import dycoke_oracle as D
+    from oracle import sttm_oracle as O
+    from sttm_amd import monkey_patch_interface as MPI
+    from sttm_amd import patch_hooks
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    C, T, H, W = 64, 6, 10, 18
+    cfg = Qwen2VLTextConfig(vocab_size=64, hidden_size=C, intermediate_size=128, num_hidden_layers=3, num_attention_heads=4,
+                            num_key_value_heads=2, max_position_embeddings=4096,
+                            rope_parameters={"rope_type": "default", "mrope_section": [2, 2, 4], "rope_theta": 10000.0})
+    cfg._attn_implementation = "sdpa"
+    model = Qwen2VLTextModel(cfg).eval().to(dev)
+    hs, start, length = _prompt(T, C, H, W, torch.float32, seed=21)
+    S = hs.shape[1]
+    pos = torch.stack([torch.arange(S), torch.arange(S) // 2, torch.arange(S) // 3]).unsqueeze(1).to(dev)     # [3, 1, S]
+    kw = {"quadtree": dict(sa_tree_thresh=0.85, sa_tree_temporal_thresh=0.6, sa_tree_root_level=1),
+          "dycoke-stage1": dict(sa_prune_ratio=0.7), "tome": dict(sa_prune_ratio=0.5, sa_tome_ver="video")}[pattern]
+    try:
+        MPI.replace_qwen2_by_sparse_attn(pattern, sa_start_layer_idx=1, **kw)
+        model.image_token_start_index = torch.tensor(start)
+        model.image_token_length = torch.tensor(length)
+        model.num_frame = torch.tensor(T)
+        model.image_H = torch.tensor(H)
+        model.image_W = torch.tensor(W)
+        with torch.inference_mode():
+            out = model(inputs_embeds=hs, position_ids=pos, use_cache=False).last_hidden_state
+            pe = model.rotary_emb(hs, pos)
+            h = model.layers[0](hs, attention_mask=None, position_embeddings=pe, position_ids=None)
+            hc, pc = h.cpu(), pos.cpu()
+            if pattern == "quadtree":
+                hm, p2, _, _ = patch_hooks.quadtree_merge_qwen2vl(hc, pc, start, length, T, H, W, O.get_quadtree_features, 0.85, 0.6, 1, False)
+            elif pattern == "dycoke-stage1":
+                hm, p2, _ = patch_hooks.dycoke_merge(hc, pc, start, length, T, D.dycoke_ttm, 0.7, gather_positions=True)
+            else:
+                hm, p2, _ = patch_hooks.tome_merge(hc, pc, start, length, T, O.get_tome_features, 0.5, "video", H=H, W=W)
+            hm, p2 = hm.to(dev), p2.to(dev)
+            pe = model.rotary_emb(hm, p2)
+            for layer in model.layers[1:]:
+                hm = layer(hm, attention_mask=None, position_embeddings=pe, position_ids=None)
+            ref = model.norm(hm)
+        assert out.shape == ref.shape and out.shape[1] < S
+        if pattern == "tome":
+            return                                   # ToMe rows may be permuted among near-tied scores (SURVEY A.5): shapes only
+        assert torch.allclose(out, ref, atol=2e-5)
+    finally:
+        MPI.restore_qwen2()
