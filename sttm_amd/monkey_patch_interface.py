@@ -32,6 +32,22 @@ def _is_prefill(past_key_values):
     return past_key_values is None or past_key_values.get_seq_length() == 0
 
 
+def _rebuild_masks(self, mask_map, hidden_states, past_key_values, position_ids=None):
+    """Masks for the SHORTER sequence after the merge.  The reference computes `causal_mask` once before the layer loop
+    and never updates it (quadtree_attn_monkey_patch.py:60-66 vs :88-117), which only works when that mask is None
+    (flash-attention / SDPA without padding).  Here the masks are rebuilt on the merged hidden states, so eager attention
+    stays causal and sliding-window layers keep their window; for SDPA / flash this returns None exactly like before."""
+    from transformers.masking_utils import create_causal_mask, create_sliding_window_causal_mask
+    # prefill: the layers from here on see an empty cache, so keys = the merged sequence itself (no past offset: the
+    # cache object already holds the LONG sequence of the earlier layers and must not be consulted); no position ids
+    # either -- gathered (non-monotonic) ids would be mistaken for packed sequences
+    mk = dict(config=self.config, inputs_embeds=hidden_states, attention_mask=None, past_key_values=None, position_ids=None)
+    out = {}
+    for k in mask_map:
+        out[k] = create_sliding_window_causal_mask(**mk) if k == "sliding_attention" else create_causal_mask(**mk)
+    return out
+
+
 def _qwen2_forward_with_merge(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None,
                               inputs_embeds=None, use_cache=None, **kwargs):
     """transformers 5.x Qwen2Model.forward + the STTM / ToMe hook (prefill, batch 1)."""
@@ -66,7 +82,7 @@ def _qwen2_forward_with_merge(self, input_ids=None, attention_mask=None, positio
                 hidden_states, position_ids, start, length, T, self.sa_pyrd_idx2size[i], type(self).sttm_resize_fn)
             self.image_token_length = torch.tensor(new_len)              # like the reference (:101): persists on the module
             position_embeddings = self.rotary_emb(hidden_states, position_ids)
-            mask_map = {k: None for k in mask_map}
+            mask_map = _rebuild_masks(self, mask_map, hidden_states, past_key_values, position_ids)
         elif (prefilling and not merged and self.sttm_pattern != "pyrd" and i == self.sa_start_layer_idx
                 and getattr(self, "image_token_length", None) is not None):
             start, length, T = _item(self.image_token_start_index), _item(self.image_token_length), _item(self.num_frame)
@@ -98,7 +114,7 @@ def _qwen2_forward_with_merge(self, input_ids=None, attention_mask=None, positio
             if self.sttm_pattern != "quadtree-abl-pos":               # that hook decides its own position embeddings
                 position_embeddings = self.rotary_emb(hidden_states, position_ids)
             # batch-1 prefill without padding: the shorter sequence is plain causal
-            mask_map = {k: None for k in mask_map}
+            mask_map = _rebuild_masks(self, mask_map, hidden_states, past_key_values, position_ids)
             merged = True
         hidden_states = layer(hidden_states, attention_mask=mask_map[self.config.layer_types[i]],
                               position_embeddings=position_embeddings, position_ids=position_ids,
@@ -157,12 +173,12 @@ def _qwen2vl_forward_with_merge(self, input_ids=None, attention_mask=None, posit
             else:
                 hidden_states, position_ids, idx = patch_hooks.tome_merge(
                     hidden_states, position_ids, start, length, T, type(self).sttm_tome_fn, self.sa_prune_ratio,
-                    self.sa_tome_ver, H=H, W=W)
+                    self.sa_tome_ver, H=H, W=W, gather_positions=True)
             if text_position_ids is not None:
                 text_position_ids = text_position_ids[..., :hidden_states.size(1)]
             self.merged_token_1d_idx = idx
             position_embeddings = self.rotary_emb(hidden_states, position_ids)
-            mask_map = {k: None for k in mask_map}          # batch-1 prefill without padding: plain causal
+            mask_map = _rebuild_masks(self, mask_map, hidden_states, past_key_values, text_position_ids)
             merged = True
         hidden_states = layer(hidden_states, attention_mask=mask_map[self.config.layer_types[i]],
                               position_embeddings=position_embeddings, position_ids=text_position_ids,

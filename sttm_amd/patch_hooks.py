@@ -67,16 +67,26 @@ def quadtree_merge_qwen2vl(hidden_states, position_ids, start, length, T, H, W, 
     return merged, pos, cache_position, idx
 
 
-def tome_merge(hidden_states, position_ids, start, length, T, merge_fn, prune_ratio, tome_ver, H=None, W=None):
-    """tome_attn_monkey_patch.py:88-107 (LLaVA: H = W = sqrt(len / T); Qwen2-VL passes H, W)."""
+def tome_merge(hidden_states, position_ids, start, length, T, merge_fn, prune_ratio, tome_ver, H=None, W=None,
+               gather_positions=False):
+    """ToMe hook.  LLaVA (token_merging_monkey_patch/tome_attn_monkey_patch.py:88-107): H = W = sqrt(len / T), position_ids
+    [B, S] are TRUNCATED to the new length (:105).  Qwen2-VL (token_merging_qwen2vl_monkey_patch/tome_attn_monkey_patch.py:
+    88-111, gather_positions=True): H, W come from the module, and the 3-D mRoPE ids [3, B, S] of the visual part are
+    GATHERED by the ToMe token index, system / instruction ids kept (:105-108)."""
     sys_f, vis_f, inst_f = split_prompt(hidden_states, start, length)
+    end = start + length
     if H is None:
         H = int(math.sqrt(length // T))
         W = (length // T) // H
     video = _video_view(vis_f[0], T, H, W)
     feat, token_idx = merge_fn(video, prune_ratio, tome_ver)
     merged = torch.cat([sys_f, feat.unsqueeze(0), inst_f], dim=1)
-    return merged, position_ids[..., :merged.size(1)], token_idx
+    if gather_positions:
+        vis_pos = position_ids[:, :, start:end][:, :, token_idx]
+        pos = torch.cat([position_ids[:, :, :start], vis_pos, position_ids[:, :, end:]], dim=-1)
+    else:
+        pos = position_ids[:, :merged.size(1)]
+    return merged, pos, token_idx
 
 
 def pyrd_resize(hidden_states, position_ids, start, length, T, tgt_size, resize_fn):

@@ -20,8 +20,8 @@ def _cases(n, seed):
         if dtype != torch.float32 and C % 2:
             continue
         root = rng.choice([-2, -1, 0, 1, 1, 1, 2])
-        thr = rng.choice([0.6, 0.75, 0.8, 0.85, 0.9, 0.95])
-        tthr = rng.choice([-1.0, 0.3, 0.5, 0.55, 0.7])
+        thr = rng.choice([0.6, 0.75, 0.8, 0.85, 0.9, 0.94, 0.95])          # 0.85 / 0.94: the run_vidqa.sh presets
+        tthr = rng.choice([-1.0, 0.3, 0.5, 0.55, 0.65, 0.7, 0.82])           # 0.55 / 0.65 / 0.82 likewise
         weighted = rng.random() < 0.25
         slow = rng.random() < 0.2 and tthr > 0
         kind = rng.choice(["synth", "smooth", "iid"])

@@ -19,11 +19,9 @@ def _prompt(T, C, H, W, dtype, n_sys=7, n_inst=11, seed=0):
 
 
 @pytest.mark.parametrize("T,C,H,W,dtype", [(8, 256, 14, 14, torch.float32), (6, 512, 14, 14, torch.bfloat16),
-                                           (4, 128, 18, 26, torch.float32)])
+                                           (4, 128, 27, 27, torch.float32)])
 def test_fused_concat_equals_three_step_hook_llava(T, C, H, W, dtype):
     from sttm_amd import get_quadtree_features, get_quadtree_features_into, patch_hooks
-    if H != W:
-        pytest.skip("the LLaVA hook assumes square frames")
     hs, start, length = _prompt(T, C, H, W, dtype)
     pos = torch.arange(hs.shape[1], device=hs.device).unsqueeze(0)
     keep = hs.clone()
@@ -175,15 +173,21 @@ def test_patched_qwen2vl_text_model_runs_on_device(pattern):
             elif pattern == "dycoke-stage1":
                 hm, p2, _ = patch_hooks.dycoke_merge(hc, pc, start, length, T, D.dycoke_ttm, 0.7, gather_positions=True)
             else:
-                hm, p2, _ = patch_hooks.tome_merge(hc, pc, start, length, T, O.get_tome_features, 0.5, "video", H=H, W=W)
+                # glue written out from token_merging_qwen2vl_monkey_patch/tome_attn_monkey_patch.py:96-108 (NOT patch_hooks):
+                # system ++ merged ++ instruction, visual mRoPE ids gathered by the ToMe token index
+                end = start + length
+                video = hc[0, start:end].reshape(T, H, W, C).permute(0, 3, 1, 2)
+                tf, tidx = O.get_tome_features(video, 0.5, "video")
+                hm = torch.cat([hc[:, :start], tf.unsqueeze(0), hc[:, end:]], dim=1)
+                p2 = torch.cat([pc[:, :, :start], pc[:, :, start:end][:, :, tidx], pc[:, :, end:]], dim=-1)
+                # ratio 0.5 merges every even token into an odd one: the output order is exact
+                assert torch.equal(model.merged_token_1d_idx.cpu(), tidx)
             hm, p2 = hm.to(dev), p2.to(dev)
             pe = model.rotary_emb(hm, p2)
             for layer in model.layers[1:]:
                 hm = layer(hm, attention_mask=None, position_embeddings=pe, position_ids=None)
             ref = model.norm(hm)
         assert out.shape == ref.shape and out.shape[1] < S
-        if pattern == "tome":
-            return                                   # ToMe rows may be permuted among near-tied scores: shapes only
         assert torch.allclose(out, ref, atol=2e-5)
     finally:
         MPI.restore_qwen2()

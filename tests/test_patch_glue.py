@@ -56,6 +56,76 @@ def test_tome_hook():
     assert tok.dtype == torch.int64
 
 
+def test_qwen2vl_tome_hook_gathers_3d_positions_by_token_index():
+    """token_merging_qwen2vl_monkey_patch/tome_attn_monkey_patch.py:105-108: system ids ++ visual ids GATHERED by the ToMe
+    token index ++ instruction ids (not a truncation).  Expected values are written out here from those lines, independently
+    of patch_hooks."""
+    T, H, W = 3, 10, 18
+    hs, start, length = _prompt(T, H, W, C=16)
+    S, end = hs.shape[1], start + length
+    pos = torch.stack([torch.arange(S), 1000 + torch.arange(S) * 2, 5000 + torch.arange(S) * 3]).unsqueeze(1)      # [3, 1, S]
+    for ratio in (0.5, 0.7):
+        out, pos2, tok = patch_hooks.tome_merge(hs, pos, start, length, T, O.get_tome_features, ratio, "video", H=H, W=W,
+                                                gather_positions=True)
+        video = hs[0, start:end].reshape(T, H, W, -1).permute(0, 3, 1, 2)
+        ef, ei = O.get_tome_features(video, ratio, "video")
+        n = ei.shape[0]
+        assert torch.equal(tok, ei) and torch.equal(out[0, start:start + n], ef)
+        assert pos2.shape == (3, 1, S - length + n)
+        expect = torch.empty(3, 1, S - length + n, dtype=pos.dtype)
+        for a in range(3):
+            for k in range(start):
+                expect[a, 0, k] = pos[a, 0, k]
+            for k in range(n):
+                expect[a, 0, start + k] = pos[a, 0, start + int(ei[k])]
+            for k in range(S - end):
+                expect[a, 0, start + n + k] = pos[a, 0, end + k]
+        assert torch.equal(pos2, expect)
+        # the instruction tokens keep their ORIGINAL ids: a truncation would have given them the visual ids
+        assert torch.equal(pos2[:, :, start + n:], pos[:, :, end:]) and not torch.equal(pos2, pos[:, :, :pos2.shape[2]])
+
+
+def test_patched_forward_stays_causal_with_eager_attention():
+    """After the merge the masks are rebuilt for the shorter sequence: with eager attention (where a None mask would mean
+    bidirectional attention) the patched forward equals the manual forward with an explicit causal mask."""
+    pytest.importorskip("transformers")
+    from transformers import Qwen2Config
+    from transformers.models.qwen2.modeling_qwen2 import Qwen2Model
+    torch.manual_seed(0)
+    C = 32
+    cfg = Qwen2Config(vocab_size=64, hidden_size=C, intermediate_size=64, num_hidden_layers=3, num_attention_heads=4,
+                      num_key_value_heads=2, max_position_embeddings=4096, attn_implementation="eager")
+    model = Qwen2Model(cfg).eval()
+    hs, start, length = _prompt(T=4, C=C)
+
+    def causal(n):
+        m = torch.full((n, n), float("-inf")).triu(1)
+        return m[None, None]
+    try:
+        MPI.replace_qwen2_by_sparse_attn("quadtree", sa_start_layer_idx=1, sa_tree_thresh=0.85, sa_tree_temporal_thresh=0.55,
+                                         sa_tree_root_level=1)
+        Qwen2Model.sttm_merge_fn = staticmethod(O.get_quadtree_features)
+        model.image_token_start_index = torch.tensor(start)
+        model.image_token_length = torch.tensor(length)
+        model.num_frame = torch.tensor(4)
+        with torch.inference_mode():
+            out = model(inputs_embeds=hs, use_cache=True).last_hidden_state        # with a cache: earlier layers hold the LONG keys
+            pos = torch.arange(hs.shape[1]).unsqueeze(0)
+            pe = model.rotary_emb(hs, pos)
+            h = model.layers[0](hs, attention_mask=causal(hs.shape[1]), position_embeddings=pe, position_ids=pos)
+            h, pos, _ = patch_hooks.quadtree_merge_llava(h, pos, start, length, 4, O.get_quadtree_features, 0.85, 0.55, 1, False)
+            pe = model.rotary_emb(h, pos)
+            for layer in model.layers[1:]:
+                h = layer(h, attention_mask=causal(h.shape[1]), position_embeddings=pe, position_ids=pos)
+            ref = model.norm(h)
+        assert out.shape == ref.shape and out.shape[1] < hs.shape[1]
+        assert torch.allclose(out, ref, atol=1e-5)
+    finally:
+        MPI.restore_qwen2()
+        if "sttm_merge_fn" in Qwen2Model.__dict__:
+            del Qwen2Model.sttm_merge_fn
+
+
 def test_installer_names_and_errors():
     for name in ("quadtree_vis", "dycoke", "nonsense"):
         with pytest.raises(NotImplementedError):
