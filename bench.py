@@ -7,17 +7,19 @@
 Workload (BASELINE.json metric): synth-v1 videos of 128 frames x 14x14 tokens x 1024 channels, fp32, in the
 production layout (channels-last view), full STTM = quadtree spatial merge (thr 0.85, root_level 1) +
 temporal merge (thr 0.55) -- the LLaVA-Video-7B / Video-MME "50 % budget" preset of the reference
-(scripts/eval/run_vidqa.sh:58).  A step = `--videos-per-step` (32) videos through get_quadtree_features, one
+(scripts/eval/run_vidqa.sh:58).  A step = `--videos-per-step` videos through get_quadtree_features, one
 after the other (the reference API is batch-1), inputs resident in HBM, outputs (incl. the host-visible
 token count) produced.  Videos are independent, so N GPUs each take their own videos (weak scaling);
-the only collective is the final all-gather of the per-video token counts over RCCL.
+the only collective is the final gather of the per-video token counts over RCCL (with --validate also the
+padded merged-token indices).
 
+`python bench.py --gpus N` without a torchrun environment spawns the N ranks itself.
 Prints ONE JSON line on rank 0 (see DESIGN.md section "Measurement" for every field).
 """
 import argparse
-import ctypes
 import json
 import os
+import socket
 import sys
 import time
 
@@ -27,7 +29,8 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-KERNELS = ["quadtree_spatial", "temporal_pairs", "labels_scan", "group_mean"]
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA = the fp32 vector rate
+KERNELS = ["quadtree_spatial", "temporal_pairs_labels", "labels_standalone", "group_mean"]
 
 
 def parse():
@@ -35,12 +38,18 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--videos-per-step", type=int, default=32)
+    ap.add_argument("--videos-per-step", type=int, default=1536,
+                    help="videos per step: 20 steps of 1536 videos keep the timed region above 2 s")
     ap.add_argument("--pool", type=int, default=8, help="distinct videos resident per GPU (> L3 capacity in total)")
     ap.add_argument("--frames", type=int, default=128)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-baseline sample")
+    ap.add_argument("--profile-calls", type=int, default=1024, help="calls of the per-kernel (HIP event) leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-batched", action="store_true", help="skip the batched-extension leg (e.g. under rocprofv3)")
+    ap.add_argument("--no-extensions", "--no-batched", dest="no_extensions", action="store_true",
+                    help="skip the batched / threaded / ToMe legs (e.g. under rocprofv3)")
+    ap.add_argument("--validate", action="store_true",
+                    help="after the timed region, all-gather the padded merged-token indices of a sample of videos over the ranks "
+                         "and check them against each rank's own recomputation")
     return ap.parse_args()
 
 
@@ -52,13 +61,25 @@ def log(msg):
         print(f"[bench +{time.perf_counter() - _T0:7.2f}s] {msg}", file=sys.stderr, flush=True)
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher of N ranks (one process per GPU, RCCL over xGMI)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and rank == 0:
-        print(f"[bench] note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    assert world == args.gpus, f"--gpus {args.gpus} but the launcher started {world} ranks"
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -68,9 +89,10 @@ def main():
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        assert dist.get_world_size() == args.gpus and dist.get_backend() == "nccl"
 
     from sttm_amd import _lib
-    from sttm_amd.quadtree_interface import get_quadtree_features, quadtree_merge_raw
+    from sttm_amd.quadtree_interface import get_quadtree_features, get_quadtree_features_batch, quadtree_merge_raw
     from sttm_amd.synth import synth_video
     lib = _lib.load()
 
@@ -117,16 +139,11 @@ def main():
         from sttm_amd.distributed import gather_counts, shard_videos
         ids = shard_videos(world * K * V, world, rank)
         all_counts = gather_counts(ids, sink, world * K * V, dev, dist)
-        t_g = time.perf_counter() - t0
         n_seen = int((all_counts > 0).sum())
         assert n_seen == world * K * V, f"gather saw {n_seen} of {world * K * V} videos"
-        t_a = time.perf_counter() - t0
     torch.cuda.synchronize()
-    t_s = time.perf_counter() - t0
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        log(f"  breakdown: issue {t_issue*1e3:.2f} gather-issued {t_g*1e3:.2f} checked {t_a*1e3:.2f} synced {t_s*1e3:.2f} barrier {elapsed*1e3:.2f} ms")
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -135,37 +152,66 @@ def main():
     value = videos / elapsed
     log(f"timed region: {videos} videos in {elapsed:.4f} s = {value:.1f} videos/s (merge calls returned after {t_issue:.4f} s)")
 
-    # ---- extension leg: the same K steps through the batched API (videos of a step issued on two side streams, so the
-    #      latency-bound label kernel of one video overlaps the bandwidth-bound kernels of the next) ----------------------
-    from sttm_amd.quadtree_interface import get_quadtree_features_batch
-    def run_step_batched(s):
-        vids = [pool[(s * V + v) % P] for v in range(V)]
-        return get_quadtree_features_batch(vids, thr, tthr, root, n_streams=int(os.environ.get("STTM_BATCH_STREAMS", "3")))
-    batched_value = None
-    if not args.no_batched:
-        run_step_batched(0)
+    def timed(fn, n_videos):
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
-        tb0 = time.perf_counter()
-        for s in range(K):
-            run_step_batched(s)
+        c0 = time.perf_counter()
+        fn()
         torch.cuda.synchronize()
         barrier()
-        tb = time.perf_counter() - tb0
+        dt = time.perf_counter() - c0
         if dist is not None:
-            tmaxb = torch.tensor([tb], dtype=torch.float64, device=dev)
-            dist.all_reduce(tmaxb, op=dist.ReduceOp.MAX)
-            tb = float(tmaxb.item())
-        batched_value = videos / tb
-        log(f"batched extension: {videos} videos in {tb:.4f} s = {batched_value:.1f} videos/s")
+            tm = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            dt = float(tm.item())
+        return world * n_videos / dt
 
-    # ---- extension leg 2: the SAME one-video-per-call API from three host threads, each on its own stream (what a serving
-    #      process with several request threads does); skipped together with the batched leg ---------------------------------
-    threaded_value = None
-    if not args.no_batched:
+    # ---- validation mode: padded merged-token indices of a sample of videos to every rank ----------------
+    validate = None
+    if args.validate:
+        from sttm_amd.distributed import gather_indices, shard_videos
+        n_val = 4 * world
+        ids_v = shard_videos(n_val, world, rank)
+        loc = []
+        for vid in ids_v:
+            x = synth_video(T, C, H, W, seed=900000 + vid, device=dev)             # CPU generator: the same tensor on every rank
+            _, _, tl = get_quadtree_features(x, thr, tthr, root)
+            loc.append(tl[:, 0] * (H * W) + tl[:, 1] * W + tl[:, 2])
+        full = gather_indices(ids_v, loc, n_val, T * H * W, dev, dist)
+        # every rank recomputes ONE video it does not own and compares it with the gathered row
+        other = (ids_v[-1] + 1) % n_val
+        x = synth_video(T, C, H, W, seed=900000 + other, device=dev)
+        _, _, tl = get_quadtree_features(x, thr, tthr, root)
+        mine = (tl[:, 0] * (H * W) + tl[:, 1] * W + tl[:, 2]).to(torch.int32)
+        row = full[other]
+        ok = bool((row[:mine.numel()] == mine).all()) and bool((row[mine.numel():] == -1).all())
+        okt = torch.tensor([1 if ok else 0], device=dev)
+        if dist is not None:
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        validate = {"videos": n_val, "index_rows_gathered": int((full[:, 0] >= 0).sum()), "cross_rank_index_match": bool(okt.item())}
+        log(f"validate: {validate}")
+
+    # ---- extension legs (identical outputs; never the headline value) ---------------------------------------------------
+    ext = {}
+    if not args.no_extensions:
+        KE = max(1, min(K, 4))
+        BATCH = 16
+
+        def run_batched():
+            for s in range(KE):
+                for b0 in range(0, V, BATCH):
+                    get_quadtree_features_batch([pool[(s * V + v) % P] for v in range(b0, min(V, b0 + BATCH))], thr, tthr, root)
+        get_quadtree_features_batch([pool[v % P] for v in range(BATCH)], thr, tthr, root)
+        ext["batched_extension"] = {
+            "value": round(timed(run_batched, KE * V), 2), "unit": "videos/s",
+            "api": f"get_quadtree_features_batch -> sttm_quadtree_merge_batch: {BATCH} videos per launch set on the caller's stream "
+                   "(not the reference's batch-1 API; identical outputs)"}
+        log(f"batched extension: {ext['batched_extension']['value']:.1f} videos/s")
+
         import threading
         NTH = 3
+
         def worker(k, n_steps):
             st = torch.cuda.Stream(device=dev)
             with torch.cuda.stream(st):
@@ -173,78 +219,92 @@ def main():
                     for v in range(k, V, NTH):
                         get_quadtree_features(pool[(s * V + v) % P], thr, tthr, root)
             st.synchronize()
+
         def run_threads(n_steps):
             th = [threading.Thread(target=worker, args=(k, n_steps)) for k in range(NTH)]
             [t.start() for t in th]
             [t.join() for t in th]
         run_threads(1)
-        torch.cuda.synchronize()
-        barrier()
-        tt0 = time.perf_counter()
-        run_threads(K)
-        torch.cuda.synchronize()
-        barrier()
-        tt = time.perf_counter() - tt0
-        if dist is not None:
-            tmaxt = torch.tensor([tt], dtype=torch.float64, device=dev)
-            dist.all_reduce(tmaxt, op=dist.ReduceOp.MAX)
-            tt = float(tmaxt.item())
-        threaded_value = videos / tt
-        log(f"threaded drop-in extension: {videos} videos in {tt:.4f} s = {threaded_value:.1f} videos/s")
+        ext["threaded_dropin_extension"] = {
+            "value": round(timed(lambda: run_threads(KE), KE * V), 2), "unit": "videos/s",
+            "api": "get_quadtree_features, one video per call, from 3 host threads with one stream each (identical outputs)"}
+        log(f"threaded drop-in extension: {ext['threaded_dropin_extension']['value']:.1f} videos/s")
 
-    # ---- roofline leg: the same K steps again with HIP events around every kernel of every call ----------
-    lib.sttm_profile_enable(1)
-    ms = (ctypes.c_float * 4)()
+        # BASELINE config 5's other half: the ToMe baseline (tome_per_video, r = 0.5) on the same 128-frame clips; MFMA-bound
+        from sttm_amd.tome_interface import get_tome_features
+        NT = 32
+        get_tome_features(pool[0], 0.5, "video")
+
+        def run_tome():
+            for v in range(NT):
+                get_tome_features(pool[v % P], 0.5, "video")
+        tome_vps = timed(run_tome, NT)
+        n_tok = T * H * W
+        flops = 2.0 * ((n_tok + 1) // 2) * (n_tok // 2) * C
+        ext["tome_extension"] = {
+            "value": round(tome_vps, 2), "unit": "videos/s", "config": f"ToMe video r=0.5, T={T} 14x14x1024 fp32",
+            "roofline": {"bound": "mfma", "achieved": round(flops * tome_vps / world / 1e12, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(flops * tome_vps / world / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                         "flops_per_video": flops, "note": "whole get_tome_features call (normalise + match + sort + merge) over the match's flops"}}
+        log(f"tome extension: {tome_vps:.1f} videos/s = {ext['tome_extension']['roofline']['achieved']} TFLOP/s")
+
+    # ---- roofline leg: per-kernel HIP events recorded by the library on the launch stream, a bounded number of calls ----
+    ev = _lib.KernelEvents()
     tot = [0.0] * 4
+    span = 0.0
     nodes = merged = leafnodes = 0
     calls = 0
-    for s in range(K):
-        for v in range(V):
-            x = pool[(s * V + v) % P]
-            _, _, _, cnt = quadtree_merge_raw(x, thr, tthr, root, False, None)
-            _lib.raise_for(lib.sttm_profile_last(ms))
-            for i in range(4):
-                tot[i] += ms[i]
-            nodes += cnt[_lib.CNT_NODES]
-            leafnodes += cnt[_lib.CNT_LEAFNODES]
-            merged += cnt[_lib.CNT_OUT]
-            calls += 1
-    lib.sttm_profile_enable(0)
+    n_prof = max(8, min(args.profile_calls, K * V))
+    for i in range(n_prof):
+        x = pool[i % P]
+        _, _, _, cnt = quadtree_merge_raw(x, thr, tthr, root, False, None, events=ev)
+        ms = ev.elapsed_ms()
+        for k in range(4):
+            tot[k] += ms[k]
+        span += sum(ms)
+        nodes += cnt[_lib.CNT_NODES]
+        leafnodes += cnt[_lib.CNT_LEAFNODES]
+        merged += cnt[_lib.CNT_OUT]
+        calls += 1
     log("roofline leg done: " + ", ".join(f"{k}={t / calls:.4f} ms" for k, t in zip(KERNELS, tot)))
     avg_ms = [t / calls for t in tot]
     n_avg, m_avg, l_avg = nodes / calls, merged / calls, leafnodes / calls
     es = 4
     thw = T * H * W
     kernel_bytes = [                                     # algorithmic (compulsory) bytes of each kernel per launch
-        es * C * thw + es * C * (n_avg - l_avg) + 16 * thw,   # read every token once, write every POOLED node once (1x1
-                                                              # nodes stay in x), meta + inverse norm + node list per token
+        es * C * thw + es * C * (n_avg - l_avg) + 24 * thw,   # read every token once, write every POOLED node once (1x1 nodes
+                                                              # stay in x), meta + inverse norm + default label / group size per token
         es * C * n_avg,                                   # every node row read once (pairs share rows)
-        4 * thw * 6,                                      # label / group / rank tables, once each
+        0.0,                                              # (stand-alone label kernel: not launched when the stage is folded)
         es * C * n_avg + es * C * m_avg,                  # read node rows, write merged rows
     ]
-    # the roofline is quoted for the dominant HBM-bound kernel; the label kernel (index 2) moves < 1 % of the bytes and is
-    # latency-bound by construction (16 workgroups), it is reported in kernel_ms but never as the roofline kernel
     dom = max((0, 1, 3), key=lambda i: avg_ms[i])
     pipeline_bytes = es * C * thw + es * C * m_avg + 24 * m_avg      # B per video
+    device_ms = span / calls                              # first event -> last event of a call: every kernel and the gaps between
     dom_gbs = kernel_bytes[dom] / (avg_ms[dom] * 1e-3) / 1e9
-    pipe_gbs = pipeline_bytes / (sum(avg_ms) * 1e-3) / 1e9
-    traffic = None
+    pipe_gbs = pipeline_bytes / (device_ms * 1e-3) / 1e9
+    # HBM traffic from the PMC counters: only if the committed passes were taken on THIS build of the library
+    traffic = traffic_tag = None
     pmc_path = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    build_tag = _lib.build_tag()
     if os.path.exists(pmc_path):
         try:
             rec = json.load(open(pmc_path))
-            if rec.get("workload") == f"T{T}_14x14x1024_f32_sttm_0.85_0.55":
-                traffic = rec.get("hbm_bytes_per_launch", {}).get(KERNELS[dom])
+            if rec.get("workload") == f"T{T}_14x14x1024_f32_sttm_0.85_0.55" and rec.get("build_tag") == build_tag:
+                traffic = rec.get("hbm_bytes_per_video")
+                traffic_tag = rec.get("tag")
         except Exception:  # noqa: BLE001
             traffic = None
     roofline = {
-        "bound": "hbm", "kernel": KERNELS[dom],
-        "achieved": round(dom_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(dom_gbs / HBM_PEAK_GBS, 4),
-        "traffic": traffic,
+        "bound": "hbm", "scope": "pipeline: all kernels of one get_quadtree_features call (SURVEY 8d: B / device time)",
+        "achieved": round(pipe_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(pipe_gbs / HBM_PEAK_GBS, 4),
+        "traffic": traffic, "traffic_profile": traffic_tag, "build_tag": build_tag,
+        "algorithmic_MB_per_video": round(pipeline_bytes / 1e6, 2), "device_ms_per_video": round(device_ms, 4),
+        "dominant_kernel": {"kernel": KERNELS[dom], "achieved": round(dom_gbs, 1), "frac": round(dom_gbs / HBM_PEAK_GBS, 4),
+                            "algorithmic_MB": round(kernel_bytes[dom] / 1e6, 2), "ms": round(avg_ms[dom], 4)},
         "kernel_ms": {k: round(v, 4) for k, v in zip(KERNELS, avg_ms)},
         "kernel_algorithmic_MB": {k: round(b / 1e6, 2) for k, b in zip(KERNELS, kernel_bytes)},
-        "pipeline": {"algorithmic_MB_per_video": round(pipeline_bytes / 1e6, 2), "device_ms_per_video": round(sum(avg_ms), 4),
-                     "achieved": round(pipe_gbs, 1), "frac": round(pipe_gbs / HBM_PEAK_GBS, 4)},
+        "profiled_calls": calls,
     }
 
     # ---- CPU baseline leg (rank 0, N = 1 only): the oracle on a bounded sample of the same workload -------
@@ -297,13 +357,10 @@ def main():
                        "api": "get_quadtree_features, one video per call (the reference's drop-in boundary)"},
             "roofline": roofline,
             "cpu_baseline": cpu,
-            "batched_extension": None if batched_value is None else {"value": round(batched_value, 2), "unit": "videos/s",
-                                  "api": "get_quadtree_features_batch: the step's videos in one call, 3 side streams "
-                                         "(not the reference's batch-1 API; identical outputs)"},
         }
-        out["threaded_dropin_extension"] = None if threaded_value is None else {
-            "value": round(threaded_value, 2), "unit": "videos/s",
-            "api": "get_quadtree_features, one video per call, from 3 host threads with one stream each (identical outputs)"}
+        out.update(ext)
+        if validate is not None:
+            out["validate"] = validate
         if cpu:
             out["index_match"] = cpu["index_exact_videos"] / max(1, cpu["videos_checked"])
         print(json.dumps(out), flush=True)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STTM_ABI_VERSION 3
+#define STTM_ABI_VERSION 4
 
 #define STTM_F32 0
 #define STTM_BF16 1
@@ -58,6 +58,8 @@ extern "C" {
 
 int sttm_abi_version(void);
 const char* sttm_last_error(void);
+/* Short hash of the sources this library was built from (measurements under profiles/ name the build they were taken on). */
+const char* sttm_build_tag(void);
 
 /* Number of pyramid levels the reference would build for this grid/root_level
  * (quadtree_builder.py:101-117), or a negative error code (STTM_ERR_INDEX / STTM_ERR_ARG). */
@@ -96,18 +98,61 @@ int sttm_quadtree_merge(const void* x, int64_t stride_t, int64_t stride_c, int64
 /*
  * Same merge, but the counts are ALSO published into `counts_host` -- int32[STTM_CNT_SLOTS] of pinned, device-mapped
  * host memory -- by the kernel that computes N' (the one before the feature gather), with slot STTM_CNT_SLOTS-1 set
- * to `seq` last (system-scope release).  sttm_wait_counts spins (no HIP call) until that slot equals seq: the caller
- * learns N' -- which it needs to size the tensors it returns -- while the feature kernel is still running, and
- * returns without a stream synchronisation; consumers of the outputs are stream-ordered as usual.
+ * to `seq` last (system-scope release).  sttm_wait_counts waits (no HIP call: a short spin, then a yielding poll) until
+ * that slot equals seq: the caller learns N' -- which it needs to size the tensors it returns -- while the feature kernel
+ * is still running, and returns without a stream synchronisation; consumers of the outputs are stream-ordered as usual.
  * counts_host may be NULL (then this is exactly sttm_quadtree_merge).
+ *
+ * events: NULL, or STTM_EVENT_SLOTS caller-created hipEvent_t handles.  The call records them on `stream` around its
+ * kernels: [0] start, [1] after the spatial kernel, [2] after the pair kernel (which also runs the label stage when that is
+ * folded into it), [3] after the stand-alone label kernel(s) (== [2] in time when there are none), [4] after the
+ * group-mean kernel.  The caller owns the events and reads them (hipEventElapsedTime) after synchronising on [4]; the
+ * library keeps no profiling state, so concurrent callers on different streams do not interfere.
  */
+#define STTM_EVENT_SLOTS 5
 int sttm_quadtree_merge_async(const void* x, int64_t stride_t, int64_t stride_c, int64_t stride_h, int64_t stride_w,
                               int T, int C, int H, int W, int dtype,
                               float threshold, float temporal_thresh, int root_level, int weighted_avg, int head_dim, int slow_ver,
                               void* workspace, size_t workspace_bytes,
                               void* feat_out, int32_t* npatch_out, int32_t* tlbr_out, int32_t* counts,
-                              int32_t* counts_host, int seq, void* stream);
+                              int32_t* counts_host, int seq, void* const* events, void* stream);
 int sttm_wait_counts(const int32_t* counts_host, int seq, int timeout_us);
+
+/*
+ * Extension (the reference API is one video per call): the same merge for `n_videos` videos of ONE shape, dtype and stride
+ * set in one set of launches -- every kernel gets a second grid dimension over the videos, so the launch ramps and tails and
+ * the latency-bound label stage of one video overlap the bandwidth-bound kernels of its neighbours.  Results are identical
+ * to n_videos separate calls.
+ *   x, feat_out, npatch_out, tlbr_out   HOST arrays of n_videos device pointers (per-video buffers as in sttm_quadtree_merge)
+ *   workspace                           n_videos * workspace_stride bytes; workspace_stride >= sttm_quadtree_workspace_bytes(...)
+ *                                       and a multiple of 256
+ *   counts                              device int32[n_videos][STTM_CNT_SLOTS]
+ *   counts_host                         NULL or pinned int32[n_videos][STTM_CNT_SLOTS]; video v publishes seq + v in its last slot
+ * Any n_videos >= 1 (internally issued in groups of STTM_BATCH_MAX videos per launch set).
+ */
+#define STTM_BATCH_MAX 16
+int sttm_quadtree_merge_batch(int n_videos, const void* const* x, int64_t stride_t, int64_t stride_c, int64_t stride_h, int64_t stride_w,
+                              int T, int C, int H, int W, int dtype,
+                              float threshold, float temporal_thresh, int root_level, int weighted_avg, int head_dim, int slow_ver,
+                              void* workspace, size_t workspace_stride,
+                              void* const* feat_out, int32_t* const* npatch_out, int32_t* const* tlbr_out, int32_t* counts,
+                              int32_t* counts_host, int seq, void* const* events, void* stream);
+
+/*
+ * Tuning and test switches (process-wide; none of them changes results).  Defaults come from the environment variable
+ * STTM_<KEY> read once at first use; sttm_configure overrides a key at run time (call it while no merge is being issued from
+ * another thread).  Returns STTM_ERR_ARG for an unknown key.  Keys:
+ *   "pairs_seg"   frames per XCD-local run of the pair kernel's workgroup map (default 16; 0 = plain order)
+ *   "pairs_nt"    pair-kernel block size (64 / 128 / 256)
+ *   "gm_split"    group-mean workgroups per frame (0 = automatic)
+ *   "label_nt"    threads per column of the stand-alone label kernels (256 / 512 / 1024)
+ *   "vec16" / "vec32"   force the pack width of 16-bit / 32-bit inputs in the spatial kernel (0 = automatic)
+ *   "fold_kb"     LDS budget (KB) per pair workgroup when the label stage runs inside the pair kernel (default 20)
+ *   "no_fold"     1: never run the label stage inside the pair kernel (stand-alone label kernel instead)
+ *   "no_fuse"     1: stand-alone label stage as two launches (no in-kernel grid barrier)
+ *   "force_gmem_labels"  1: label stage on global scratch instead of LDS (the path of columns too large for LDS)
+ */
+int sttm_configure(const char* key, int value);
 
 /*
  * Position-embedding ablation (pos_embs argument of get_quadtree_features; quadtree_spatial_merger.py:88-153,
@@ -120,15 +165,6 @@ int sttm_quadtree_apply(const void* v, int64_t stride_t, int64_t stride_c, int64
                         int T, int Cv, int H, int W, int dtype_v, int sum_mode,
                         int C_feat, int dtype_feat, int root_level, void* workspace, size_t workspace_bytes,
                         const int32_t* counts, void* out, void* stream);
-
-/*
- * Per-kernel timing of sttm_quadtree_merge for the benchmark's roofline leg (not part of the reference API).
- * While enabled, every call records hipEvents on its stream around its four kernels;
- * sttm_profile_last waits for the last call and writes milliseconds for
- * {spatial, pairs, labels, group_mean} into ms_host[4] (HOST memory).
- */
-int sttm_profile_enable(int on);
-int sttm_profile_last(float* ms_host);
 
 /*
  * Label propagation on an explicit edge list: replaces get_merge_dst_idx_safe

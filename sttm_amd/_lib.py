@@ -7,28 +7,33 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsttm_hip.so")
+# STTM_LIB=dev selects the development build (python -m sttm_amd.build --dev: measurement hooks for tools/, never the product)
+LIB_PATH = os.path.join(_HERE, "lib", "libsttm_hip_dev.so" if os.environ.get("STTM_LIB") == "dev" else "libsttm_hip.so")
 
 STTM_F32, STTM_BF16, STTM_F16 = 0, 1, 2
 ERR_ARG, ERR_UNSUPPORTED, ERR_LAUNCH, ERR_INDEX, ERR_PARITY, ERR_TIMEOUT = -1, -2, -3, -4, -5, -6
-ABI_VERSION = 3            # STTM_ABI_VERSION of include/sttm_hip.h this binding was written for
+ABI_VERSION = 4            # STTM_ABI_VERSION of include/sttm_hip.h this binding was written for
 CNT_NODES, CNT_CANDIDATES, CNT_EDGES, CNT_OUT, CNT_ITERS, CNT_OVERFLOW, CNT_LEAFNODES, CNT_SLOTS = 0, 1, 2, 3, 4, 5, 6, 8
+EVENT_SLOTS = 5            # STTM_EVENT_SLOTS
+BATCH_MAX = 16             # STTM_BATCH_MAX
 
 # every symbol include/sttm_hip.h declares, with its ctypes signature
 _vp, _i, _i64, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
 SIGNATURES = {
     "sttm_abi_version": (_i, []),
     "sttm_last_error": (ctypes.c_char_p, []),
+    "sttm_build_tag": (ctypes.c_char_p, []),
     "sttm_quadtree_num_levels": (_i, [_i, _i, _i]),
     "sttm_quadtree_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "sttm_quadtree_merge": (_i, [_vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _f, _i, _i, _i, _i,
                                  _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     "sttm_quadtree_merge_async": (_i, [_vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _f, _i, _i, _i, _i,
-                                       _vp, _sz, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+                                       _vp, _sz, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "sttm_quadtree_merge_batch": (_i, [_i, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _f, _i, _i, _i, _i,
+                                       _vp, _sz, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "sttm_configure": (_i, [ctypes.c_char_p, _i]),
     "sttm_wait_counts": (_i, [_vp, _i, _i]),
     "sttm_quadtree_apply": (_i, [_vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp]),
-    "sttm_profile_enable": (_i, [_i]),
-    "sttm_profile_last": (_i, [ctypes.POINTER(ctypes.c_float)]),
     "sttm_merge_dst_idx": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "sttm_tome_workspace_bytes": (_sz, [_i, _i, _i]),
     "sttm_tome_step": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -65,6 +70,17 @@ def load():
     return lib
 
 
+def configure(**kw):
+    """Tuning / test switches of the library (sttm_configure); none changes results."""
+    lib = load()
+    for k, v in kw.items():
+        raise_for(lib.sttm_configure(k.encode(), int(v)))
+
+
+def build_tag():
+    return load().sttm_build_tag().decode()
+
+
 def last_error():
     return load().sttm_last_error().decode("utf-8", "replace")
 
@@ -83,6 +99,51 @@ def raise_for(code):
     if code == ERR_ARG:
         raise ValueError(msg)
     raise RuntimeError(f"libsttm_hip error {code}: {msg}")
+
+
+class KernelEvents:
+    """STTM_EVENT_SLOTS caller-owned hipEvent_t handles for the `events` argument of sttm_quadtree_merge_async / _batch
+    (per-kernel timing: the library records them on the launch stream, the caller reads them).  The HIP entry points are
+    resolved through the library's own dependency on libamdhip64, i.e. the runtime instance the kernels run on."""
+    NAMES = ("spatial", "pairs", "labels", "group_mean")
+
+    def __init__(self):
+        lib = load()
+        self._create, self._sync, self._elapsed = lib.hipEventCreate, lib.hipEventSynchronize, lib.hipEventElapsedTime
+        self._destroy = lib.hipEventDestroy
+        self._create.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        self._sync.argtypes = [ctypes.c_void_p]
+        self._destroy.argtypes = [ctypes.c_void_p]
+        self._elapsed.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+        self.handles = (ctypes.c_void_p * EVENT_SLOTS)()
+        for i in range(EVENT_SLOTS):
+            ev = ctypes.c_void_p()
+            if self._create(ctypes.byref(ev)) != 0:
+                raise RuntimeError("hipEventCreate failed")
+            self.handles[i] = ev
+
+    def pointer(self):
+        return ctypes.cast(self.handles, ctypes.c_void_p)
+
+    def elapsed_ms(self):
+        """Wait for the last event and return the milliseconds of the four intervals (NAMES)."""
+        if self._sync(self.handles[EVENT_SLOTS - 1]) != 0:
+            raise RuntimeError("hipEventSynchronize failed")
+        out = []
+        for i in range(EVENT_SLOTS - 1):
+            ms = ctypes.c_float()
+            if self._elapsed(ctypes.byref(ms), self.handles[i], self.handles[i + 1]) != 0:
+                raise RuntimeError("hipEventElapsedTime failed")
+            out.append(ms.value)
+        return out
+
+    def __del__(self):
+        try:
+            for h in self.handles:
+                if h:
+                    self._destroy(h)
+        except Exception:      # noqa: BLE001  -- interpreter shutdown
+            pass
 
 
 class BoundedCache(dict):

@@ -1,6 +1,6 @@
 """Build libsttm_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
-    python -m sttm_amd.build [--force] [--verbose]
+    python -m sttm_amd.build [--force] [--verbose] [--dev]
 
 The library lands in sttm_amd/lib/libsttm_hip.so; it is git-ignored but travels with the tree.
 """
@@ -35,16 +35,38 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > mt for d in deps)
 
 
-def build(force=False, verbose=False, extra_flags=()):
+def source_tag():
+    """Short hash of every source the library is built from: baked into the library (sttm_build_tag) so that measurements
+    committed under profiles/ can say which build they were taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES) + sorted(HEADERS):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:12]
+
+
+def build(force=False, verbose=False, extra_flags=(), dev=False):
+    """dev=True builds libsttm_hip_dev.so with -DSTTM_DEV (the measurement hooks of tools/*_ticks.py, tools/k1_ablate.py);
+    the product library never contains them."""
     os.makedirs(LIBDIR, exist_ok=True)
+    objdir = os.path.join(LIBDIR, "dev") if dev else LIBDIR
+    os.makedirs(objdir, exist_ok=True)
+    lib = os.path.join(LIBDIR, "libsttm_hip_dev.so") if dev else LIB
+    if dev:
+        extra_flags = tuple(extra_flags) + ("-DSTTM_DEV",)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    tag = source_tag() + ("-dev" if dev else "")
+    tag_file = os.path.join(objdir, ".build_tag")
+    old_tag = open(tag_file).read().strip() if os.path.exists(tag_file) else ""
     objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
-        if force or _stale(o, [s] + hdrs):
-            jobs.append([_hipcc(), *FLAGS, *extra_flags, "-c", s, "-o", o])
+        extra = [f'-DSTTM_BUILD_TAG="{tag}"'] if src == "api.hip" else []
+        if force or _stale(o, [s] + hdrs) or (extra and old_tag != tag):
+            jobs.append([_hipcc(), *FLAGS, *extra_flags, *extra, "-c", s, "-o", o])
     def run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)
@@ -55,10 +77,12 @@ def build(force=False, verbose=False, extra_flags=()):
             print(r.stderr)
     with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB, objs):
-        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
-    return LIB
+    if force or jobs or _stale(lib, objs):
+        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs])
+    with open(tag_file, "w") as fh:
+        fh.write(tag + "\n")
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv, dev="--dev" in sys.argv))

@@ -5,23 +5,13 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <sched.h>
 
 #include "sttm_kernels.h"
 
 namespace {
 
 thread_local char g_err[512] = "";
-
-// Optional per-kernel timing (bench.py's roofline leg): hipEvents recorded on the launch stream around
-// each kernel of sttm_quadtree_merge.  Off by default; costs nothing when off.
-constexpr int kProfSlots = 4;             // spatial, pairs, labels, group_mean
-bool g_prof_on = false;
-hipEvent_t g_prof_ev[kProfSlots + 1];
-bool g_prof_have = false, g_prof_valid = false, g_prof_ran[kProfSlots];
-
-void prof_mark(int i, hipStream_t s) {
-    if (g_prof_on) hipEventRecord(g_prof_ev[i], s);
-}
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -30,6 +20,37 @@ int fail(int code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
+
+// Tuning / test switches: defaults from STTM_<KEY> environment variables, read ONCE; sttm_configure overrides them.
+// None of them changes results.
+struct Config {
+    int pairs_seg, pairs_nt, gm_split, label_nt, vec16, vec32, fold_kb, no_fold, no_fuse, force_gmem_labels;
+};
+int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+Config& config() {
+    static Config c = [] {
+        Config d;
+        d.pairs_seg = env_int("STTM_PAIRS_SEG", 16);
+        d.pairs_nt = env_int("STTM_PAIRS_NT", 256);
+        d.gm_split = env_int("STTM_GM_SPLIT", 0);
+        d.label_nt = env_int("STTM_LABEL_NT", 1024);
+        d.vec16 = env_int("STTM_VEC16", 0);
+        d.vec32 = env_int("STTM_VEC32", 0);
+        d.fold_kb = env_int("STTM_FOLD_KB", 20);
+        d.no_fold = env_int("STTM_NO_FOLD", 0);
+        d.no_fuse = env_int("STTM_NO_FUSE", env_int("STTM_NO_FUSE_LABELS", 0));
+        d.force_gmem_labels = env_int("STTM_FORCE_GMEM_LABELS", 0);
+        return d;
+    }();
+    return c;
+}
+
+#ifdef STTM_DEV
+sttm::DevHooks g_dev = {};
+#endif
 
 inline int ceil_half(int v) { return (v + 1) / 2; }
 
@@ -78,7 +99,7 @@ struct Carve {
 
 struct Plan {
     sttm::LevelDims dims;
-    int R, rc_stride, ecap, N, max_slots;
+    int R, rc_stride, ecap, N, max_slots, max_area;
     size_t bytes;
 };
 
@@ -97,11 +118,11 @@ void root_extent_host(const sttm::LevelDims& g, int I, int J, int* ah, int* aw) 
 
 struct Buffers {
     char* S; uint32_t* meta; double* inrm; int* rc_list;
-    int32_t *edges; float* edge_sim; int32_t *edge_cnt, *cand_cnt; unsigned long long* col_mask; int32_t *frame_cnt, *bar, *colscratch;
-    int32_t *grp_np, *grp_cnt, *grp_off, *members;
+    int32_t *edges; float* edge_sim; int32_t *edge_cnt, *cand_cnt; unsigned long long* col_mask; int32_t *col_arrive, *frame_cnt, *bar, *colscratch;
+    int32_t *lab_row, *gcnt;
 };
 
-size_t carve_all(const Plan& p, int T, int C, int dtype, char* base, Buffers* b) {
+size_t carve_all(const Plan& p, int T, int H, int W, int C, int dtype, char* base, Buffers* b) {
     Carve c{base, 0};
     const size_t N = (size_t)p.N;
     const size_t nfr = (size_t)(T > 1 ? T - 1 : 1) * p.R;
@@ -116,13 +137,12 @@ size_t carve_all(const Plan& p, int T, int C, int dtype, char* base, Buffers* b)
     o.edge_cnt = c.take<int32_t>(nfr * 4);
     o.cand_cnt = c.take<int32_t>(nfr * 4);
     o.col_mask = c.take<unsigned long long>((size_t)p.R * 8);
+    o.col_arrive = c.take<int32_t>((size_t)p.R * 4);
     o.frame_cnt = c.take<int32_t>((size_t)T * 4);
     o.bar = c.take<int32_t>(16);
-    o.colscratch = c.take<int32_t>(N * 20);
-    o.grp_np = c.take<int32_t>(N * 4);
-    o.grp_cnt = c.take<int32_t>(N * 4);
-    o.grp_off = c.take<int32_t>(N * 4);
-    o.members = c.take<int32_t>(N * 4);
+    o.colscratch = c.take<int32_t>(sttm::colscratch_ints(T, H, W, p.R) * 4);
+    o.lab_row = c.take<int32_t>(N * 4);
+    o.gcnt = c.take<int32_t>(N * 4);
     return c.off;
 }
 
@@ -137,21 +157,23 @@ int make_plan(int T, int H, int W, int C, int dtype, int root_level, Plan* p) {
             root_extent_host(p->dims, I, J, &ah, &aw);
             if (ah * aw > max_area) max_area = ah * aw;
         }
+    p->max_area = max_area;
     p->rc_stride = 1 + max_area;
     p->ecap = 2 * max_area;
     p->N = T * H * W;
     p->max_slots = T * max_area;
-    p->bytes = carve_all(*p, T, C, dtype, nullptr, nullptr);
+    p->bytes = carve_all(*p, T, H, W, C, dtype, nullptr, nullptr);
     return D;
 }
 
 int pick_vec(int C, int dtype, const void* x, int64_t sT, int64_t sH, int64_t sW, int* nt, bool allow_wide16 = false) {
     const int eb = elem_bytes(dtype);
+    const Config& cfg = config();
     if (allow_wide16 && dtype != STTM_F32) {
         // 32-byte packs for rows that need 5-8 waves with 16-byte packs (2048 < C <= 4096): four waves per root cell instead
         // of seven halve the per-wave reduction butterflies.  Measured on T=128 bf16: C=3584 75.1 -> 65.0 us; no gain at
-        // C=8192 (16 -> 8 waves) and a loss at C=2048 (4 -> 2 waves), hence the window.  STTM_VEC16=8 / 16 force a width.
-        static const int want = [] { const char* e = getenv("STTM_VEC16"); return e ? atoi(e) : 0; }();
+        // C=8192 (16 -> 8 waves) and a loss at C=2048 (4 -> 2 waves), hence the window.  vec16 = 8 / 16 force a width.
+        const int want = cfg.vec16;
         const int w8 = (C / 8 + 63) / 64;
         const bool window = C % 8 == 0 && w8 > 4 && w8 <= 8;
         if ((want == 16 || (want == 0 && window)) && C % 16 == 0 && reinterpret_cast<uintptr_t>(x) % 32 == 0 &&
@@ -162,7 +184,7 @@ int pick_vec(int C, int dtype, const void* x, int64_t sT, int64_t sH, int64_t sW
     }
     if (allow_wide16 && dtype == STTM_F32) {
         // same idea for fp32 (32-byte packs); window mirrors the 16-bit one (5-8 waves with 16-byte packs: 1024 < C <= 2048)
-        static const int want32 = [] { const char* e = getenv("STTM_VEC32"); return e ? atoi(e) : 0; }();
+        const int want32 = cfg.vec32;
         const int w4 = (C / 4 + 63) / 64;
         const bool window = C % 4 == 0 && w4 > 4 && w4 <= 8;
         if ((want32 == 8 || (want32 == 0 && window)) && C % 8 == 0 && reinterpret_cast<uintptr_t>(x) % 32 == 0 &&
@@ -173,12 +195,9 @@ int pick_vec(int C, int dtype, const void* x, int64_t sT, int64_t sH, int64_t sW
     }
     // 16 bytes per lane for every dtype.  For 16-bit inputs the 8-wide pack became affordable (128 VGPRs) once the
     // dot products moved to v_dot2c_f32_bf16/f16; measured on T=128, C=3584 bf16: spatial 107 -> 84 us,
-    // group mean 69 -> 51 us, pairs 42 -> 31 us versus 4-wide packs (STTM_VEC16=4 restores them).
+    // group mean 69 -> 51 us, pairs 42 -> 31 us versus 4-wide packs (vec16 = 4 restores them).
     int cands_f32[] = {4, 2, 1}, cands_16[] = {8, 4, 2};
-    {
-        const char* pv = getenv("STTM_VEC16");
-        if (pv && atoi(pv) == 4) { cands_16[0] = 4; cands_16[1] = 8; }
-    }
+    if (cfg.vec16 == 4) { cands_16[0] = 4; cands_16[1] = 8; }
     const int* cands = dtype == STTM_F32 ? cands_f32 : cands_16;
     for (int k = 0; k < 3; ++k) {
         const int v = cands[k];
@@ -249,7 +268,7 @@ int octree_plan(int B, int side, int C, int dtype, int root_level, OctPlan* p) {
 
 // Group-mean workgroups per frame: enough 4-wave workgroups (T * split) to cover the chip several times over.
 int gm_split_for(int T) {
-    static const int env = [] { const char* e = getenv("STTM_GM_SPLIT"); return e ? atoi(e) : 0; }();
+    const int env = config().gm_split;
     const int want = env > 0 ? env : (4096 + T - 1) / T;
     int s = 1;
     while (s < want && s < 64) s <<= 1;          // a power of two: the kernel masks instead of dividing
@@ -259,21 +278,191 @@ int gm_split_for(int T) {
 // Pack width of the row-streaming kernels (pairs, group mean): they only read / write whole [*, C] rows, so fp32 can use
 // 8-wide packs (two 16-byte loads in flight per lane; measured 23.7 -> 20.0 us for the group mean) even though the spatial
 // kernel keeps 4-wide packs for occupancy.  Per-head cosine keeps the spatial kernel's width (head lanes are defined on it).
-int row_vec(int C, int dtype, int spatial_vec, bool dense_x, const void* x, int head_dim) {
+int row_vec(int C, int dtype, int spatial_vec, bool dense_x, bool aligned32, int head_dim) {
     if (dtype != STTM_F32 && spatial_vec == 16) return 8;          // the row kernels have no 32-byte 16-bit packs
-    if (dtype == STTM_F32 && spatial_vec == 8) return (C % 8 == 0 && !(dense_x && reinterpret_cast<uintptr_t>(x) % 32)) ? 8 : 4;
+    if (dtype == STTM_F32 && spatial_vec == 8) return (C % 8 == 0 && !(dense_x && !aligned32)) ? 8 : 4;
     if (dtype != STTM_F32 || head_dim != 0 || spatial_vec != 4) return spatial_vec;
     if (C % 8 || C < 512) return spatial_vec;
-    if (dense_x && reinterpret_cast<uintptr_t>(x) % 32) return spatial_vec;
+    if (dense_x && !aligned32) return spatial_vec;
     return 8;
+}
+
+void mark(void* const* events, int i, hipStream_t s) {
+    if (events && events[i]) hipEventRecord(reinterpret_cast<hipEvent_t>(events[i]), s);
+}
+
+// The merge of up to kBatchMax same-shaped videos in one set of launches.
+int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c, int64_t stride_h, int64_t stride_w,
+                int T, int C, int H, int W, int dtype,
+                float threshold, float temporal_thresh, int root_level, int weighted_avg, int head_dim, int slow_ver,
+                void* workspace, size_t workspace_stride,
+                void* const* feat_out, int32_t* const* npatch_out, int32_t* const* tlbr_out, int32_t* counts,
+                int32_t* counts_host, int seq, void* const* events, hipStream_t stream) {
+    if (!x || !workspace || !feat_out || !npatch_out || !tlbr_out || !counts) return fail(STTM_ERR_ARG, "null pointer argument");
+    if (T < 1 || C < 1) return fail(STTM_ERR_ARG, "T and C must be positive");
+    if (dtype < 0 || dtype > 2) return fail(STTM_ERR_ARG, "unknown dtype code %d", dtype);
+    if (stride_c != 1) return fail(STTM_ERR_ARG, "channel stride must be 1 (channels-last view); got %lld", (long long)stride_c);
+    if (H > 255 || W > 255) return fail(STTM_ERR_UNSUPPORTED, "token grids larger than 255 per side are not supported");
+    if ((int64_t)T * H * W >= (1ll << 31) / 16) return fail(STTM_ERR_UNSUPPORTED, "too many tokens");
+    if (head_dim < 0 || (head_dim > 0 && C % head_dim)) return fail(STTM_ERR_ARG, "head_dim %d does not divide C = %d", head_dim, C);
+    Plan p;
+    const int D = make_plan(T, H, W, C, dtype, root_level, &p);
+    if (D < 0) return D;
+    if (workspace_stride < p.bytes) return fail(STTM_ERR_ARG, "workspace too small: %zu < %zu", workspace_stride, p.bytes);
+    if (reinterpret_cast<uintptr_t>(workspace) % 256 || (nv > 1 && workspace_stride % 256))
+        return fail(STTM_ERR_ARG, "workspace (and the per-video stride) must be 256-byte aligned");
+    if (weighted_avg) {
+        for (int l = 1; l < D; ++l)
+            if ((p.dims.h[l] & 1) != (p.dims.w[l] & 1))
+                return fail(STTM_ERR_PARITY, "weighted_avg needs equal parities at every pooled level; level %dx%d is mixed",
+                            p.dims.h[l], p.dims.w[l]);
+    }
+    if (p.max_area > 32767) return fail(STTM_ERR_UNSUPPORTED, "root cells of %d leaves (limit 32767)", p.max_area);
+    // multiply-high divisions of the label stage: j / ecap for j < (T-1)*ecap needs (T-1) * ecap^2 <= 2^32
+    if ((double)(T > 1 ? T - 1 : 1) * p.ecap * (double)p.ecap > 4294967296.0)
+        return fail(STTM_ERR_UNSUPPORTED, "T * (root-cell area)^2 too large for the label stage (T=%d, area=%d)", T, p.max_area);
+    sttm::BatchPtrs bp;
+    memset(&bp, 0, sizeof(bp));
+    bp.ws_stride = workspace_stride;
+    uintptr_t all_bits = 0;
+    for (int v = 0; v < nv; ++v) {
+        if (!x[v] || !feat_out[v] || !npatch_out[v] || !tlbr_out[v]) return fail(STTM_ERR_ARG, "null per-video pointer (video %d)", v);
+        bp.x[v] = x[v]; bp.feat[v] = feat_out[v]; bp.npatch[v] = npatch_out[v]; bp.tlbr[v] = tlbr_out[v];
+        all_bits |= reinterpret_cast<uintptr_t>(x[v]);
+    }
+    const void* x_align = reinterpret_cast<const void*>(all_bits);      // the least aligned of the inputs decides the pack width
+    int nt = 0;
+    const int vec = pick_vec(C, dtype, x_align, stride_t, stride_h, stride_w, &nt, head_dim == 0);
+    if (!vec) return fail(STTM_ERR_UNSUPPORTED, "C=%d with this alignment does not fit one workgroup (need C/vec <= 1024 lanes)", C);
+
+    int n_head = 0, head_lanes = 0;
+    if (head_dim > 0) {
+        // one head = head_dim / vec adjacent lanes: must be a power of two that fits a wave
+        if (head_dim % vec) return fail(STTM_ERR_UNSUPPORTED, "head_dim %d is not a multiple of the %d-wide channel pack", head_dim, vec);
+        head_lanes = head_dim / vec;
+        if (head_lanes > 64 || (head_lanes & (head_lanes - 1)))
+            return fail(STTM_ERR_UNSUPPORTED, "head_dim / pack width = %d lanes: need a power of two <= 64", head_lanes);
+        n_head = C / head_dim;
+    }
+    const Config& cfg = config();
+    Buffers b;
+    carve_all(p, T, H, W, C, dtype, reinterpret_cast<char*>(workspace), &b);
+    sttm::SpatialArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.x = x[0]; sa.sT = stride_t; sa.sH = stride_h; sa.sW = stride_w;
+    sa.T = T; sa.H = H; sa.W = W; sa.C = C;
+    sa.dims = p.dims;
+    sa.threshold = threshold;
+    sa.thr_lo_sq = thr_lo_sq_of(threshold);
+    sa.sum_mode = weighted_avg ? 1 : 0;
+    sa.n_head = n_head; sa.head_lanes = head_lanes;
+    // dense [T*H*W, C] input: the rows of 1x1 nodes are read from x by the later kernels instead of being copied to S
+    const bool dense = stride_w == C && stride_h == (int64_t)W * C && stride_t == (int64_t)H * W * C;
+    sa.leaves_in_x = dense ? 1 : 0;
+    sa.S = b.S; sa.meta = b.meta; sa.inrm = b.inrm; sa.rc_list = b.rc_list;
+    sa.rc_stride = p.rc_stride;
+    sa.lab_row = b.lab_row; sa.gcnt = b.gcnt;
+    sa.counts = counts;
+    sa.frame_cnt = b.frame_cnt;
+    sa.bar = b.bar;
+    sa.col_arrive = b.col_arrive;
+
+    sttm::TemporalArgs ta;
+    memset(&ta, 0, sizeof(ta));
+    ta.T = T; ta.H = H; ta.W = W; ta.C = C; ta.R = p.R;
+    ta.dims = p.dims;
+    ta.dtype = dtype; ta.vec = row_vec(C, dtype, vec, dense, all_bits % 32 == 0, head_dim);
+    ta.pairs_seg = cfg.pairs_seg >= 0 ? cfg.pairs_seg : 16;
+    if (ta.pairs_seg > T - 1) ta.pairs_seg = T - 1 > 0 ? T - 1 : 0;
+    ta.pairs_nt = (cfg.pairs_nt == 64 || cfg.pairs_nt == 128) ? cfg.pairs_nt : 256;
+    ta.label_nt = (cfg.label_nt == 256 || cfg.label_nt == 512) ? cfg.label_nt : 1024;
+    ta.temporal_thresh = temporal_thresh;
+    ta.weighted_avg = weighted_avg ? 1 : 0;
+    // slow_ver has no per-head variant upstream (cross_frame_node_merging_slow ignores head_dim)
+    ta.n_head = slow_ver ? 0 : n_head; ta.head_lanes = slow_ver ? 0 : head_lanes;
+    ta.inline_norms = (slow_ver && n_head > 0) ? 1 : 0;
+    ta.slow_ver = slow_ver ? 1 : 0;
+    ta.max_slots = p.max_slots;
+    ta.force_gmem = cfg.force_gmem_labels ? 1 : 0;
+    ta.no_fuse = cfg.no_fuse ? 1 : 0;
+    ta.no_fold = cfg.no_fold ? 1 : 0;
+    ta.fold_kb = cfg.fold_kb > 0 ? cfg.fold_kb : 20;
+    ta.S = b.S; ta.xrows = dense ? x[0] : nullptr; ta.meta = b.meta; ta.inrm = b.inrm; ta.rc_list = b.rc_list; ta.rc_stride = p.rc_stride;
+    ta.edges = b.edges; ta.edge_sim = slow_ver ? b.edge_sim : nullptr; ta.ecap = p.ecap; ta.edge_cnt = b.edge_cnt; ta.cand_cnt = b.cand_cnt;
+    ta.ecap_magic = 0xffffffffu / (unsigned)p.ecap + 1u;
+    ta.col_mask = b.col_mask; ta.col_arrive = b.col_arrive; ta.frame_cnt = b.frame_cnt; ta.bar = b.bar;
+    ta.colscratch = b.colscratch;
+    ta.gm_split = gm_split_for(T); ta.lab_row = b.lab_row; ta.gcnt = b.gcnt;
+    ta.counts = counts;
+    ta.counts_host = counts_host; ta.seq = seq;
+    ta.feat_out = feat_out[0]; ta.npatch_out = npatch_out[0]; ta.tlbr_out = tlbr_out[0];
+#ifdef STTM_DEV
+    sa.dev = g_dev; ta.dev = g_dev;
+#endif
+
+    const bool pairs = temporal_thresh > 0.f && T > 1;
+    int fold_cap = 0;
+    ta.fold_labels = (pairs && sttm::labels_can_fold(ta, nv, &fold_cap)) ? 1 : 0;
+    ta.fold_cap = fold_cap;
+
+    hipError_t e;
+    mark(events, 0, stream);
+    if ((e = sttm::launch_spatial(sa, bp, nv, dtype, vec, nt, stream)) != hipSuccess)
+        return fail(STTM_ERR_LAUNCH, "spatial kernel: %s", hipGetErrorString(e));
+    mark(events, 1, stream);
+#ifdef STTM_DEV
+    if (g_dev.k1_mode == 1 || g_dev.k1_mode == 2) {      // ablation run: only the spatial kernel is launched, outputs are not valid
+        for (int i = 2; i < STTM_EVENT_SLOTS; ++i) mark(events, i, stream);
+        return STTM_OK;
+    }
+#endif
+    if (pairs) {
+        if ((e = sttm::launch_pairs(ta, bp, nv, stream)) != hipSuccess)
+            return fail(STTM_ERR_LAUNCH, "pairs kernel: %s", hipGetErrorString(e));
+    }
+    if (pairs && slow_ver) {
+        if ((e = sttm::launch_slow_filter(ta, bp, nv, stream)) != hipSuccess)
+            return fail(e == hipErrorInvalidValue ? STTM_ERR_UNSUPPORTED : STTM_ERR_LAUNCH, "slow_ver filter kernel: %s", hipGetErrorString(e));
+    }
+    mark(events, 2, stream);
+    if (!ta.fold_labels) {
+        if (sttm::labels_can_fuse(ta, nv)) {
+            if ((e = sttm::launch_labels_fused(ta, bp, nv, stream)) != hipSuccess)
+                return fail(STTM_ERR_LAUNCH, "fused label kernel: %s", hipGetErrorString(e));
+        } else if ((e = sttm::launch_col_labels(ta, bp, nv, true, stream)) != hipSuccess ||
+                   (e = sttm::launch_col_labels(ta, bp, nv, false, stream)) != hipSuccess)
+            return fail(STTM_ERR_LAUNCH, "label kernels: %s", hipGetErrorString(e));
+    }
+    mark(events, 3, stream);
+    if ((e = sttm::launch_group_mean(ta, bp, nv, stream)) != hipSuccess)
+        return fail(STTM_ERR_LAUNCH, "group-mean kernel: %s", hipGetErrorString(e));
+    mark(events, 4, stream);
+    return STTM_OK;
 }
 
 }  // namespace
 
 extern "C" {
 
+#ifndef STTM_BUILD_TAG
+#define STTM_BUILD_TAG "untagged"
+#endif
 int sttm_abi_version(void) { return STTM_ABI_VERSION; }
+const char* sttm_build_tag(void) { return STTM_BUILD_TAG; }
 const char* sttm_last_error(void) { return g_err; }
+
+int sttm_configure(const char* key, int value) {
+    if (!key) return fail(STTM_ERR_ARG, "null key");
+    Config& c = config();
+    struct { const char* name; int* slot; } keys[] = {
+        {"pairs_seg", &c.pairs_seg}, {"pairs_nt", &c.pairs_nt}, {"gm_split", &c.gm_split}, {"label_nt", &c.label_nt},
+        {"vec16", &c.vec16}, {"vec32", &c.vec32}, {"fold_kb", &c.fold_kb}, {"no_fold", &c.no_fold}, {"no_fuse", &c.no_fuse},
+        {"force_gmem_labels", &c.force_gmem_labels},
+    };
+    for (auto& k : keys)
+        if (!strcmp(key, k.name)) { *k.slot = value; return STTM_OK; }
+    return fail(STTM_ERR_ARG, "unknown configuration key '%s'", key);
+}
 
 int sttm_quadtree_num_levels(int H, int W, int root_level) {
     sttm::LevelDims d;
@@ -295,7 +484,47 @@ int sttm_quadtree_merge(const void* x, int64_t stride_t, int64_t stride_c, int64
                         void* stream_) {
     return sttm_quadtree_merge_async(x, stride_t, stride_c, stride_h, stride_w, T, C, H, W, dtype, threshold, temporal_thresh,
                                      root_level, weighted_avg, head_dim, slow_ver, workspace, workspace_bytes, feat_out, npatch_out,
-                                     tlbr_out, counts, nullptr, 0, stream_);
+                                     tlbr_out, counts, nullptr, 0, nullptr, stream_);
+}
+
+int sttm_quadtree_merge_async(const void* x, int64_t stride_t, int64_t stride_c, int64_t stride_h, int64_t stride_w,
+                              int T, int C, int H, int W, int dtype,
+                              float threshold, float temporal_thresh, int root_level, int weighted_avg, int head_dim, int slow_ver,
+                              void* workspace, size_t workspace_bytes,
+                              void* feat_out, int32_t* npatch_out, int32_t* tlbr_out, int32_t* counts,
+                              int32_t* counts_host, int seq, void* const* events, void* stream_) {
+    return merge_group(1, &x, stride_t, stride_c, stride_h, stride_w, T, C, H, W, dtype, threshold, temporal_thresh, root_level,
+                       weighted_avg, head_dim, slow_ver, workspace, workspace_bytes, &feat_out, &npatch_out, &tlbr_out, counts,
+                       counts_host, seq, events, reinterpret_cast<hipStream_t>(stream_));
+}
+
+int sttm_quadtree_merge_batch(int n_videos, const void* const* x, int64_t stride_t, int64_t stride_c, int64_t stride_h, int64_t stride_w,
+                              int T, int C, int H, int W, int dtype,
+                              float threshold, float temporal_thresh, int root_level, int weighted_avg, int head_dim, int slow_ver,
+                              void* workspace, size_t workspace_stride,
+                              void* const* feat_out, int32_t* const* npatch_out, int32_t* const* tlbr_out, int32_t* counts,
+                              int32_t* counts_host, int seq, void* const* events, void* stream_) {
+    if (n_videos < 1) return fail(STTM_ERR_ARG, "n_videos must be >= 1");
+    if (!x || !feat_out || !npatch_out || !tlbr_out || !counts || !workspace) return fail(STTM_ERR_ARG, "null pointer argument");
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    for (int v0 = 0; v0 < n_videos; v0 += STTM_BATCH_MAX) {
+        const int nv = n_videos - v0 < STTM_BATCH_MAX ? n_videos - v0 : STTM_BATCH_MAX;
+        // the caller's events bracket the whole call: the start comes from the first group, the rest from the last
+        void* ev[STTM_EVENT_SLOTS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        if (events) {
+            if (v0 == 0) ev[0] = events[0];
+            if (v0 + nv >= n_videos)
+                for (int i = 1; i < STTM_EVENT_SLOTS; ++i) ev[i] = events[i];
+        }
+        const int rc = merge_group(nv, x + v0, stride_t, stride_c, stride_h, stride_w, T, C, H, W, dtype, threshold, temporal_thresh,
+                                   root_level, weighted_avg, head_dim, slow_ver,
+                                   reinterpret_cast<char*>(workspace) + (size_t)v0 * workspace_stride, workspace_stride,
+                                   feat_out + v0, npatch_out + v0, tlbr_out + v0, counts + (size_t)v0 * STTM_CNT_SLOTS,
+                                   counts_host ? counts_host + (size_t)v0 * STTM_CNT_SLOTS : nullptr, seq + v0,
+                                   events ? ev : nullptr, stream);
+        if (rc != STTM_OK) return rc;
+    }
+    return STTM_OK;
 }
 
 int sttm_quadtree_apply(const void* v, int64_t stride_t, int64_t stride_c, int64_t stride_h, int64_t stride_w,
@@ -320,7 +549,7 @@ int sttm_quadtree_apply(const void* v, int64_t stride_t, int64_t stride_c, int64
     const int vec = pick_vec(Cv, dtype_v, v, stride_t, stride_h, stride_w, &nt);
     if (!vec) return fail(STTM_ERR_UNSUPPORTED, "channel count / alignment of the side tensor is not supported");
     Buffers b;
-    carve_all(p, T, C_feat, dtype_feat, reinterpret_cast<char*>(workspace), &b);
+    carve_all(p, T, H, W, C_feat, dtype_feat, reinterpret_cast<char*>(workspace), &b);
     const bool dense = stride_w == Cv && stride_h == (int64_t)W * Cv && stride_t == (int64_t)H * W * Cv;
     sttm::SpatialArgs sa;
     memset(&sa, 0, sizeof(sa));
@@ -336,18 +565,24 @@ int sttm_quadtree_apply(const void* v, int64_t stride_t, int64_t stride_c, int64
     sttm::TemporalArgs ta;
     memset(&ta, 0, sizeof(ta));
     ta.T = T; ta.H = H; ta.W = W; ta.C = Cv; ta.R = p.R;
+    ta.dims = p.dims;
     ta.dtype = dtype_v; ta.vec = vec;
     ta.weighted_avg = sum_mode ? 1 : 0;
     ta.S = b.S; ta.xrows = dense ? v : nullptr;
-    ta.frame_cnt = b.frame_cnt; ta.grp_np = b.grp_np; ta.grp_cnt = b.grp_cnt; ta.grp_off = b.grp_off; ta.members = b.members;
+    ta.frame_cnt = b.frame_cnt; ta.lab_row = b.lab_row; ta.gcnt = b.gcnt;
     ta.meta = b.meta; ta.gm_split = gm_split_for(T);
     ta.counts = const_cast<int32_t*>(counts);
     ta.feat_out = out;
-    if ((e = sttm::launch_group_mean(ta, stream)) != hipSuccess)
+    sttm::BatchPtrs bp;
+    memset(&bp, 0, sizeof(bp));
+    bp.x[0] = v; bp.feat[0] = out;
+    if ((e = sttm::launch_group_mean(ta, bp, 1, stream)) != hipSuccess)
         return fail(STTM_ERR_LAUNCH, "group-mean kernel: %s", hipGetErrorString(e));
     return STTM_OK;
 }
 
+// The wait for N': a short busy spin (the counts usually arrive within tens of microseconds), then a yielding poll so that
+// a long kernel queue ahead of this call does not burn a core.
 int sttm_wait_counts(const int32_t* counts_host, int seq, int timeout_us) {
     if (!counts_host) return fail(STTM_ERR_ARG, "null pointer");
     const volatile int32_t* flag = counts_host + STTM_CNT_SLOTS - 1;
@@ -356,163 +591,27 @@ int sttm_wait_counts(const int32_t* counts_host, int seq, int timeout_us) {
     for (unsigned spins = 0;; ++spins) {
         if (*flag == seq) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return STTM_OK; }
         __builtin_ia32_pause();
-        if ((spins & 1023u) == 1023u) {
+        if ((spins & 255u) == 255u) {
             clock_gettime(CLOCK_MONOTONIC, &t1);
             const long long us = (t1.tv_sec - t0.tv_sec) * 1000000ll + (t1.tv_nsec - t0.tv_nsec) / 1000;
             if (us > timeout_us) return STTM_ERR_TIMEOUT;
+            if (us > 300) sched_yield();
         }
     }
 }
 
-int sttm_quadtree_merge_async(const void* x, int64_t stride_t, int64_t stride_c, int64_t stride_h, int64_t stride_w,
-                              int T, int C, int H, int W, int dtype,
-                              float threshold, float temporal_thresh, int root_level, int weighted_avg, int head_dim, int slow_ver,
-                              void* workspace, size_t workspace_bytes,
-                              void* feat_out, int32_t* npatch_out, int32_t* tlbr_out, int32_t* counts,
-                              int32_t* counts_host, int seq, void* stream_) {
-    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-    if (!x || !workspace || !feat_out || !npatch_out || !tlbr_out || !counts) return fail(STTM_ERR_ARG, "null pointer argument");
-    if (T < 1 || C < 1) return fail(STTM_ERR_ARG, "T and C must be positive");
-    if (dtype < 0 || dtype > 2) return fail(STTM_ERR_ARG, "unknown dtype code %d", dtype);
-    if (stride_c != 1) return fail(STTM_ERR_ARG, "channel stride must be 1 (channels-last view); got %lld", (long long)stride_c);
-    if (H > 255 || W > 255) return fail(STTM_ERR_UNSUPPORTED, "token grids larger than 255 per side are not supported");
-    if ((int64_t)T * H * W >= (1ll << 31) / 8) return fail(STTM_ERR_UNSUPPORTED, "too many tokens");
-    if (head_dim < 0 || (head_dim > 0 && C % head_dim)) return fail(STTM_ERR_ARG, "head_dim %d does not divide C = %d", head_dim, C);
-    Plan p;
-    const int D = make_plan(T, H, W, C, dtype, root_level, &p);
-    if (D < 0) return D;
-    if (workspace_bytes < p.bytes) return fail(STTM_ERR_ARG, "workspace too small: %zu < %zu", workspace_bytes, p.bytes);
-    if (reinterpret_cast<uintptr_t>(workspace) % 256) return fail(STTM_ERR_ARG, "workspace must be 256-byte aligned");
-    if (weighted_avg) {
-        for (int l = 1; l < D; ++l)
-            if ((p.dims.h[l] & 1) != (p.dims.w[l] & 1))
-                return fail(STTM_ERR_PARITY, "weighted_avg needs equal parities at every pooled level; level %dx%d is mixed",
-                            p.dims.h[l], p.dims.w[l]);
-    }
-    int nt = 0;
-    const int vec = pick_vec(C, dtype, x, stride_t, stride_h, stride_w, &nt, head_dim == 0);
-    if (!vec) return fail(STTM_ERR_UNSUPPORTED, "C=%d with this alignment does not fit one workgroup (need C/vec <= 1024 lanes)", C);
-
-    if (p.max_slots > 65536)
-        return fail(STTM_ERR_UNSUPPORTED, "T * (root-cell area) = %d exceeds 65536 label slots per column", p.max_slots);
-    int n_head = 0, head_lanes = 0;
-    if (head_dim > 0) {
-        // one head = head_dim / vec adjacent lanes: must be a power of two that fits a wave
-        if (head_dim % vec) return fail(STTM_ERR_UNSUPPORTED, "head_dim %d is not a multiple of the %d-wide channel pack", head_dim, vec);
-        head_lanes = head_dim / vec;
-        if (head_lanes > 64 || (head_lanes & (head_lanes - 1)))
-            return fail(STTM_ERR_UNSUPPORTED, "head_dim / pack width = %d lanes: need a power of two <= 64", head_lanes);
-        n_head = C / head_dim;
-    }
-    Buffers b;
-    carve_all(p, T, C, dtype, reinterpret_cast<char*>(workspace), &b);
-    sttm::SpatialArgs sa;
-    memset(&sa, 0, sizeof(sa));
-    sa.x = x; sa.sT = stride_t; sa.sH = stride_h; sa.sW = stride_w;
-    sa.T = T; sa.H = H; sa.W = W; sa.C = C;
-    sa.dims = p.dims;
-    sa.threshold = threshold;
-    {
-        // `sim_f32 >= threshold_f32` <=> `sim >= lo`: lo = midpoint below the fp32 threshold (exclusive when the
-        // tie would round down to the predecessor, i.e. when the threshold's mantissa is odd)
-        sa.thr_lo_sq = thr_lo_sq_of(threshold);
-    }
-    sa.sum_mode = weighted_avg ? 1 : 0;
-    sa.n_head = n_head; sa.head_lanes = head_lanes;
-    // dense [T*H*W, C] input: the rows of 1x1 nodes are read from x by the later kernels instead of being copied to S
-    const bool dense = stride_w == C && stride_h == (int64_t)W * C && stride_t == (int64_t)H * W * C;
-    sa.leaves_in_x = dense ? 1 : 0;
-    {
-        const char* np = getenv("STTM_PIPELINE");
-        sa.pipeline = (np && np[0] == '1') ? 1 : 0;
-        const char* dm = getenv("STTM_K1_ABLATE");      // only honoured by the profile leg: results are invalid
-        sa.dbg_mode = (dm && g_prof_on) ? atoi(dm) : 0;
-        const char* kt = getenv("STTM_K1_TICKS");            // stamps land at the start of the column scratch (unused by K1)
-        const char* kw = getenv("STTM_K1_TICKS_WG");
-        sa.dbg_ticks = (kt && kt[0] == '1') ? reinterpret_cast<long long*>(b.colscratch) + 32 : nullptr;
-        sa.dbg_wg = kw ? atoi(kw) : 0;
-    }
-    sa.S = b.S; sa.meta = b.meta; sa.inrm = b.inrm; sa.rc_list = b.rc_list;
-    sa.rc_stride = p.rc_stride;
-    sa.counts = counts;
-    sa.frame_cnt = b.frame_cnt;
-    sa.bar = b.bar;
-
-    sttm::TemporalArgs ta;
-    memset(&ta, 0, sizeof(ta));
-    ta.T = T; ta.H = H; ta.W = W; ta.C = C; ta.R = p.R;
-    ta.dims = p.dims;
-    ta.dtype = dtype; ta.vec = row_vec(C, dtype, vec, dense, x, head_dim);
-    {
-        static const int seg_env = [] { const char* e = getenv("STTM_PAIRS_SEG"); return e ? atoi(e) : -1; }();
-        ta.pairs_seg = seg_env >= 0 ? seg_env : 16;
-        if (ta.pairs_seg > T - 1) ta.pairs_seg = T - 1 > 0 ? T - 1 : 0;
-    }
-    ta.temporal_thresh = temporal_thresh;
-    ta.weighted_avg = weighted_avg ? 1 : 0;
-    // slow_ver has no per-head variant upstream (cross_frame_node_merging_slow ignores head_dim)
-    ta.n_head = slow_ver ? 0 : n_head; ta.head_lanes = slow_ver ? 0 : head_lanes;
-    ta.inline_norms = (slow_ver && n_head > 0) ? 1 : 0;
-    ta.slow_ver = slow_ver ? 1 : 0;
-    ta.max_slots = p.max_slots;
-    {
-        const char* fg = getenv("STTM_FORCE_GMEM_LABELS");
-        ta.force_gmem = (fg && fg[0] == '1') ? 1 : 0;
-    }
-    ta.S = b.S; ta.xrows = dense ? x : nullptr; ta.meta = b.meta; ta.inrm = b.inrm; ta.rc_list = b.rc_list; ta.rc_stride = p.rc_stride;
-    ta.edges = b.edges; ta.edge_sim = slow_ver ? b.edge_sim : nullptr; ta.ecap = p.ecap; ta.edge_cnt = b.edge_cnt; ta.cand_cnt = b.cand_cnt;
-    ta.col_mask = b.col_mask; ta.frame_cnt = b.frame_cnt; ta.bar = b.bar;
-    {
-        const char* nf = getenv("STTM_NO_FUSE_LABELS");
-        ta.no_fuse = (nf && nf[0] == '1') ? 1 : 0;
-        const char* tk = getenv("STTM_LABEL_TICKS");       // debug: stamps land in the first bytes of feat_out
-        const char* tw = getenv("STTM_LABEL_TICKS_WG");
-        ta.dbg_wg = tw ? atoi(tw) : 0;
-        ta.dbg_ticks = (tk && tk[0] == '1') ? reinterpret_cast<long long*>(b.colscratch) : nullptr;
-        const char* k2 = getenv("STTM_K2_TICKS");
-        const char* k2w = getenv("STTM_K2_TICKS_WG");
-        ta.dbg_ticks_k2 = (k2 && k2[0] == '1') ? reinterpret_cast<long long*>(b.colscratch) + 64 : nullptr;
-        ta.dbg_wg_k2 = k2w ? atoi(k2w) : 0;
-    } ta.colscratch = b.colscratch;
-    ta.gm_split = gm_split_for(T); ta.grp_np = b.grp_np; ta.grp_cnt = b.grp_cnt; ta.grp_off = b.grp_off; ta.members = b.members;
-    ta.counts = counts;
-    ta.counts_host = counts_host; ta.seq = seq;
-    ta.feat_out = feat_out; ta.npatch_out = npatch_out; ta.tlbr_out = tlbr_out;
-
-    hipError_t e;
-    g_prof_valid = false;
-    prof_mark(0, stream);
-    if ((e = sttm::launch_spatial(sa, dtype, vec, nt, stream)) != hipSuccess)
-        return fail(STTM_ERR_LAUNCH, "spatial kernel: %s", hipGetErrorString(e));
-    prof_mark(1, stream);
-    if (sa.dbg_mode == 1 || sa.dbg_mode == 2) {          // ablation run: only the spatial kernel was launched, its outputs are not valid
-        for (int i = 2; i <= kProfSlots; ++i) prof_mark(i, stream);
-        g_prof_valid = true; g_prof_ran[0] = true; g_prof_ran[1] = g_prof_ran[2] = g_prof_ran[3] = false;
-        return STTM_OK;
-    }
-    const bool pairs = temporal_thresh > 0.f && T > 1;
-    if (pairs) {
-        if ((e = sttm::launch_pairs(ta, stream)) != hipSuccess)
-            return fail(STTM_ERR_LAUNCH, "pairs kernel: %s", hipGetErrorString(e));
-    }
-    if (pairs && slow_ver) {
-        if ((e = sttm::launch_slow_filter(ta, stream)) != hipSuccess)
-            return fail(e == hipErrorInvalidValue ? STTM_ERR_UNSUPPORTED : STTM_ERR_LAUNCH, "slow_ver filter kernel: %s", hipGetErrorString(e));
-    }
-    prof_mark(2, stream);
-    if (sttm::labels_can_fuse(ta)) {
-        if ((e = sttm::launch_labels_fused(ta, stream)) != hipSuccess)
-            return fail(STTM_ERR_LAUNCH, "fused label kernel: %s", hipGetErrorString(e));
-    } else if ((e = sttm::launch_col_labels(ta, true, stream)) != hipSuccess ||
-               (e = sttm::launch_col_labels(ta, false, stream)) != hipSuccess)
-        return fail(STTM_ERR_LAUNCH, "label kernels: %s", hipGetErrorString(e));
-    prof_mark(3, stream);
-    if ((e = sttm::launch_group_mean(ta, stream)) != hipSuccess)
-        return fail(STTM_ERR_LAUNCH, "group-mean kernel: %s", hipGetErrorString(e));
-    prof_mark(4, stream);
-    if (g_prof_on) { g_prof_valid = true; g_prof_ran[0] = true; g_prof_ran[1] = pairs; g_prof_ran[2] = true; g_prof_ran[3] = true; }
+#ifdef STTM_DEV
+// development build only (not in the public header): measurement hooks of tools/*_ticks.py and tools/k1_ablate.py.
+// ticks: device buffer of >= 48 long longs -- [0, 16) spatial workgroup k1_wg, [16, 32) pair workgroup k2_wg, [32, 48) label
+// stage of column lbl_col -- or NULL to switch the stamps off.
+int sttm_dev_hooks(int k1_mode, long long* ticks, int k1_wg, int k2_wg, int lbl_col) {
+    g_dev.k1_mode = k1_mode;
+    g_dev.k1_ticks = ticks; g_dev.k1_wg = k1_wg;
+    g_dev.k2_ticks = ticks ? ticks + 16 : nullptr; g_dev.k2_wg = k2_wg;
+    g_dev.lbl_ticks = ticks ? ticks + 32 : nullptr; g_dev.lbl_col = lbl_col;
     return STTM_OK;
 }
+#endif
 
 int sttm_pool2d_out_side(int side, int stride, int mode) {
     if (side < 1 || stride < 1 || mode < STTM_POOL_AVERAGE || mode > STTM_POOL_BILINEAR) return fail(STTM_ERR_ARG, "bad side/stride/mode");
@@ -615,39 +714,6 @@ int sttm_octree_build(const void* x, int n_cubes, int side, int C, int dtype, fl
     while (vec > (eb == 4 ? 1 : 2) && (C % vec || align % (vec * eb))) vec >>= 1;
     hipError_t e = sttm::launch_octree(a, dtype, vec, ws + p.off_scan, p.scan_bytes, reinterpret_cast<hipStream_t>(stream_));
     if (e != hipSuccess) return fail(STTM_ERR_LAUNCH, "octree kernels: %s", hipGetErrorString(e));
-    return STTM_OK;
-}
-
-// debug helper (not in the public header): byte offset of the column scratch inside the workspace
-size_t sttm_debug_colscratch_offset(int T, int H, int W, int C, int dtype, int root_level) {
-    Plan p;
-    if (make_plan(T, H, W, C, dtype, root_level, &p) < 0) return 0;
-    Buffers b;
-    carve_all(p, T, C, dtype, nullptr, &b);
-    return reinterpret_cast<size_t>(b.colscratch);
-}
-
-int sttm_profile_enable(int on) {
-    if (on && !g_prof_have) {
-        for (int i = 0; i <= kProfSlots; ++i)
-            if (hipEventCreate(&g_prof_ev[i]) != hipSuccess) return fail(STTM_ERR_LAUNCH, "hipEventCreate failed");
-        g_prof_have = true;
-    }
-    g_prof_on = on != 0;
-    g_prof_valid = false;
-    return STTM_OK;
-}
-
-int sttm_profile_last(float* ms_host) {
-    if (!ms_host) return fail(STTM_ERR_ARG, "null output");
-    if (!g_prof_valid) return fail(STTM_ERR_ARG, "no profiled sttm_quadtree_merge call to report");
-    if (hipEventSynchronize(g_prof_ev[kProfSlots]) != hipSuccess) return fail(STTM_ERR_LAUNCH, "hipEventSynchronize failed");
-    for (int i = 0; i < kProfSlots; ++i) {
-        float ms = 0.f;
-        if (g_prof_ran[i] && hipEventElapsedTime(&ms, g_prof_ev[i], g_prof_ev[i + 1]) != hipSuccess)
-            return fail(STTM_ERR_LAUNCH, "hipEventElapsedTime failed");
-        ms_host[i] = g_prof_ran[i] ? ms : 0.f;
-    }
     return STTM_OK;
 }
 

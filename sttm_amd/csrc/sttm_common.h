@@ -20,6 +20,11 @@ __host__ __device__ __forceinline__ int child_count(int i, int n_child) {
     return ((n_child & 1) && i == 0) ? 1 : 2;
 }
 
+// inverse of child_start / child_count: the parent index of child c along an axis whose child level has n_child cells
+__host__ __device__ __forceinline__ int parent_of(int c, int n_child) {
+    return (n_child & 1) ? (c == 0 ? 0 : (c + 1) / 2) : c / 2;
+}
+
 struct LevelDims {
     int n_level;              // pyramid levels built, root level first (index 0), leaf last
     int h[kMaxLevels + 1];

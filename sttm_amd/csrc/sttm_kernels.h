@@ -5,6 +5,37 @@
 
 namespace sttm {
 
+// Measurement hooks (wall_clock64 stamps of single workgroups, ablation modes) exist only in the development build
+// (-DSTTM_DEV, `python -m sttm_amd.build --dev` -> libsttm_hip_dev.so); the product library carries none of them.
+#ifdef STTM_DEV
+struct DevHooks {
+    int k1_mode;              // spatial-kernel ablation: 1 = stop after the statistics, 2 = loads + pooling only (outputs invalid)
+    long long* k1_ticks;      // stamps of spatial workgroup k1_wg
+    int k1_wg;
+    long long* k2_ticks;      // stamps of pair workgroup k2_wg
+    int k2_wg;
+    long long* lbl_ticks;     // stamps of the label stage of column lbl_col
+    int lbl_col;
+};
+#define STTM_DEV_TICK(hooks, field, sel, n) \
+    do { if ((hooks).field && (sel) && threadIdx.x == 0) (hooks).field[n] = wall_clock64(); } while (0)
+#else
+#define STTM_DEV_TICK(hooks, field, sel, n) do { } while (0)
+#endif
+
+// Per-video buffers of one launch set (blockIdx.y = video): the kernels take their arguments for video 0 and shift them.
+constexpr int kBatchMax = STTM_BATCH_MAX;
+struct BatchPtrs {
+    const void* x[kBatchMax];
+    void* feat[kBatchMax];
+    int32_t* npatch[kBatchMax];
+    int32_t* tlbr[kBatchMax];
+    size_t ws_stride;         // bytes between the workspaces of consecutive videos
+};
+template <typename P> __device__ __forceinline__ void shift_ptr(P*& p, size_t bytes) {
+    if (p) p = reinterpret_cast<P*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<P>::type*>(p)) + bytes);
+}
+
 struct SpatialArgs {
     const void* x;            // [T, H, W, C] memory (channels-last view of the logical [T, C, H, W])
     int64_t sT, sH, sW;       // element strides; the channel stride is 1
@@ -15,22 +46,32 @@ struct SpatialArgs {
     int sum_mode;             // weighted_avg: sum-pool pyramid
     int n_head;               // 0 = whole-vector cosine; > 0 = per-head cosine averaged over n_head heads
     int head_lanes;           // head_dim / vec: adjacent lanes that own one head (power of two <= 64)
-    int pipeline;             // opt-in: persistent software-pipelined 3-level kernel (measured slower on MI355X)
-    int dbg_mode;             // ablation (sttm_debug_spatial_ms only): 1 = stop after the statistics, 2 = loads + pooling only
-    long long* dbg_ticks;     // measurement tool only (STTM_K1_TICKS=1): wall_clock64 stamps of workgroup dbg_wg, else null
-    int dbg_wg;
     int leaves_in_x;          // x is a dense [T*H*W, C] matrix: 1x1 nodes are NOT copied to S (consumers read x)
     // outputs
     void* S;                  // [T*H*W, C] node features at their origin rows (input dtype)
     uint32_t* meta;           // [T*H*W] 0 = no node starts here, else (y2 << 16) | x2
     double* inrm;             // [T*H*W] 1 / (|node feature| + 1e-8) for the temporal cosine
-    int* rc_list;             // [T*R][rc_stride]: count, then packed (y1<<24 | x1<<16 | y2<<8 | x2)
+    int* rc_list;             // [T*R][rc_stride]: count | (1x1 count << 16), then packed (y1<<24 | x1<<16 | y2<<8 | x2)
     int rc_stride;
+    int32_t* lab_row;         // [T*H*W] default labels: a node's own origin row, -1 where no node starts
+    int32_t* gcnt;            // [T*H*W] default group sizes: 1 at a node's origin row, else 0
     int32_t* counts;          // STTM_CNT_* slots (zeroed here, filled by the later kernels)
-    int32_t* frame_cnt;       // [T] zeroed here for the label kernels
-    int32_t* bar;             // [4] zeroed here: [0] grid-barrier counter of the fused label kernel, [2..3] the 64-bit arrival/total word
+    int32_t* frame_cnt;       // [T] zeroed here for the label stage
+    int32_t* bar;             // [4] zeroed here: [0] grid-barrier counter of the label stage, [2..3] the 64-bit arrival/total word
+    int32_t* col_arrive;      // [R] zeroed here: pair workgroups of a column that have published their edges
+#ifdef STTM_DEV
+    DevHooks dev;
+#endif
 };
-hipError_t launch_spatial(const SpatialArgs& a, int dtype, int vec, int nt, hipStream_t stream);
+__device__ __forceinline__ void rebase(SpatialArgs& a, const BatchPtrs& bp, int v) {
+    a.x = bp.x[v];
+    if (v == 0) return;
+    const size_t off = (size_t)v * bp.ws_stride;
+    shift_ptr(a.S, off); shift_ptr(a.meta, off); shift_ptr(a.inrm, off); shift_ptr(a.rc_list, off); shift_ptr(a.lab_row, off);
+    shift_ptr(a.gcnt, off); shift_ptr(a.frame_cnt, off); shift_ptr(a.bar, off); shift_ptr(a.col_arrive, off);
+    a.counts += (size_t)v * STTM_CNT_SLOTS;
+}
+hipError_t launch_spatial(const SpatialArgs& a, const BatchPtrs& bp, int n_videos, int dtype, int vec, int nt, hipStream_t stream);
 hipError_t launch_node_apply(const SpatialArgs& a, int dtype, int vec, int nt, hipStream_t stream);
 
 struct TemporalArgs {
@@ -43,7 +84,7 @@ struct TemporalArgs {
     int slow_ver;
     int weighted_avg;
     int max_slots;            // T * (largest root-cell area in leaves)
-    int force_gmem;           // debug/test: run the label kernels on the global-memory path
+    int force_gmem;           // option: run the label stage on the global-memory path
     const void* S;
     const void* xrows;        // non-null: x as a dense [T*H*W, C] matrix; rows of 1x1 nodes live there, not in S
     const uint32_t* meta;
@@ -51,41 +92,61 @@ struct TemporalArgs {
     const int* rc_list;
     int rc_stride;
     // scratch
-    int32_t* edges;           // [R][T-1][ecap] kept edges, packed column-local slots (dst << 16 | src), dst = earlier frame
+    int32_t* edges;           // [R][T-1][ecap] kept edges of one frame pair: (leaf offset in the earlier frame's root cell << 16) |
+                              // leaf offset in the later frame's; the first edge_cnt entries of a list are valid
     int ecap;
+    unsigned ecap_magic;      // ceil(2^32 / ecap): j / ecap for j < (T-1) * ecap
     int pairs_seg;            // k_pairs workgroup map: frames per XCD-local segment (0 = plain t-major order)
+    int pairs_nt;             // k_pairs block size
     float* edge_sim;          // [R][T-1][ecap] similarity of each kept edge (slow_ver only, else null)
     int32_t* edge_cnt;        // [R][T-1]
     int32_t* cand_cnt;        // [R][T-1]
     unsigned long long* col_mask;   // [R] per-column idempotency history (bit k = idempotent after iteration k+1)
+    int32_t* col_arrive;      // [R] arrivals of a column's pair workgroups (zeroed by the spatial kernel)
     int32_t* frame_cnt;       // [T] survivors per frame (zeroed by the spatial kernel)
-    int32_t* bar;             // [2] grid-barrier counters of the fused label kernel (zeroed by the spatial kernel)
-    int no_fuse;              // debug/test: use the three-kernel label path
-    int dbg_wg;               // debug: which workgroup stamps
-    long long* dbg_ticks;     // debug: wall_clock64 stamps of workgroup 0 at phase boundaries (null = off)
-    long long* dbg_ticks_k2;  // debug (STTM_K2_TICKS=1): stamps of pair-kernel workgroup dbg_wg_k2
-    int dbg_wg_k2;
-    int32_t* colscratch;      // [5*T*H*W] label arrays of columns that do not fit LDS
+    int32_t* bar;             // [4] grid-barrier counter + arrival word (zeroed by the spatial kernel)
+    int no_fuse, no_fold;     // options: two-launch label path / no label stage inside the pair kernel
+    int fold_kb;              // LDS budget (KB) of a pair workgroup when the label stage is folded in
+    int fold_labels;          // the last pair workgroup of a column to arrive runs that column's label stage
+    int fold_cap;             // ... with room for this many active nodes / kept edges in LDS (global scratch beyond)
+    int label_nt;             // threads per column workgroup of the stand-alone label kernels
+    int32_t* colscratch;      // label arrays of columns that do not fit LDS
     int gm_split;             // group-mean workgroups per frame
-    int32_t* grp_np;          // [T*H*W] by origin row: patches covered by the group
-    int32_t* grp_cnt;         // [T*H*W] by origin row; 0 = not a survivor
-    int32_t* grp_off;         // [T*H*W] by origin row
-    int32_t* members;         // [T*H*W] origin rows (| leaf bit), grouped, ascending inside a group
+    int32_t* lab_row;         // [T*H*W] by origin row: origin row of the node's representative (-1: no node starts here)
+    int32_t* gcnt;            // [T*H*W] by origin row: members of the group this node represents; 0 = not a survivor
     int32_t* counts;
-    int32_t* counts_host;     // optional host-mapped (pinned) mirror of counts, published by the label kernel with slot 7 = seq
+    int32_t* counts_host;     // optional host-mapped (pinned) mirror of counts, published by the label stage with slot 7 = seq
     int seq;
     // outputs
     void* feat_out;
     int32_t* npatch_out;
     int32_t* tlbr_out;
+#ifdef STTM_DEV
+    DevHooks dev;
+#endif
 };
-hipError_t launch_pairs(const TemporalArgs& a, hipStream_t stream);
-hipError_t launch_slow_filter(const TemporalArgs& a, hipStream_t stream);
-hipError_t launch_col_labels(const TemporalArgs& a, bool probe, hipStream_t stream);
-bool labels_can_fuse(const TemporalArgs& a);
-hipError_t launch_labels_fused(const TemporalArgs& a, hipStream_t stream);
-hipError_t launch_group_mean(const TemporalArgs& a, hipStream_t stream);
-bool col_labels_use_gmem(const TemporalArgs& a);
+__device__ __forceinline__ void rebase(TemporalArgs& a, const BatchPtrs& bp, int v) {
+    if (a.xrows) a.xrows = bp.x[v];
+    a.feat_out = bp.feat[v]; a.npatch_out = bp.npatch[v]; a.tlbr_out = bp.tlbr[v];
+    if (v == 0) return;
+    const size_t off = (size_t)v * bp.ws_stride;
+    shift_ptr(a.S, off); shift_ptr(a.meta, off); shift_ptr(a.inrm, off); shift_ptr(a.rc_list, off);
+    shift_ptr(a.edges, off); shift_ptr(a.edge_sim, off); shift_ptr(a.edge_cnt, off); shift_ptr(a.cand_cnt, off);
+    shift_ptr(a.col_mask, off); shift_ptr(a.col_arrive, off); shift_ptr(a.frame_cnt, off); shift_ptr(a.bar, off);
+    shift_ptr(a.colscratch, off); shift_ptr(a.lab_row, off); shift_ptr(a.gcnt, off);
+    a.counts += (size_t)v * STTM_CNT_SLOTS;
+    if (a.counts_host) a.counts_host += (size_t)v * STTM_CNT_SLOTS;
+    a.seq += v;
+}
+// every launcher takes the arguments of video 0 plus the per-video buffers; n_videos <= kBatchMax
+hipError_t launch_pairs(const TemporalArgs& a, const BatchPtrs& bp, int n_videos, hipStream_t stream);
+hipError_t launch_slow_filter(const TemporalArgs& a, const BatchPtrs& bp, int n_videos, hipStream_t stream);
+hipError_t launch_col_labels(const TemporalArgs& a, const BatchPtrs& bp, int n_videos, bool probe, hipStream_t stream);
+bool labels_can_fuse(const TemporalArgs& a, int n_videos);
+bool labels_can_fold(const TemporalArgs& a, int n_videos, int* cap);
+hipError_t launch_labels_fused(const TemporalArgs& a, const BatchPtrs& bp, int n_videos, hipStream_t stream);
+hipError_t launch_group_mean(const TemporalArgs& a, const BatchPtrs& bp, int n_videos, hipStream_t stream);
+size_t colscratch_ints(int T, int H, int W, int R);
 
 hipError_t launch_pool2d(const void* x, void* out, int T, int H, int W, int C, int OH, int OW, int stride, int mode, int dtype,
                          hipStream_t stream);

@@ -32,3 +32,26 @@ def gather_counts(local_ids, local_counts, n_videos, device, dist=None):
         # disjoint ownership: a SUM all-reduce of the one-hot-by-owner vector is an all-gather with static shape
         dist.all_reduce(full, op=dist.ReduceOp.SUM)
     return full
+
+
+def gather_indices(local_ids, local_indices, n_videos, max_len, device, dist=None):
+    """Validation mode of SURVEY 8(e)(ii): every rank learns every video's merged-token indices (t*H*W + y1*W + x1, int32),
+    for the cross-rank parity check and token-ratio statistics.  Returns int32 [n_videos, max_len], rows padded with -1.
+    local_indices: this rank's index tensors, in the order of local_ids.  ONE all-gather of a padded
+    [videos per rank, 1 + max_len] block (column 0 = video id); features never travel."""
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    per_rank = (n_videos + world - 1) // world
+    block = torch.full((per_rank, 1 + max_len), -1, dtype=torch.int32, device=device)
+    for k, (vid, idx) in enumerate(zip(local_ids, local_indices)):
+        if idx.numel() > max_len:
+            raise ValueError(f"video {vid}: {idx.numel()} indices do not fit max_len={max_len}")
+        block[k, 0] = vid
+        block[k, 1:1 + idx.numel()] = idx.to(device=device, dtype=torch.int32)
+    if world > 1:
+        parts = [torch.empty_like(block) for _ in range(world)]
+        dist.all_gather(parts, block)
+        block = torch.cat(parts, dim=0)
+    full = torch.full((n_videos, max_len), -1, dtype=torch.int32, device=device)
+    owned = block[:, 0] >= 0
+    full[block[owned, 0].long()] = block[owned, 1:]
+    return full

@@ -5,6 +5,9 @@ reference's `token_merging_utils/quadtree_interface.py:5-13` (which forwards to
 `quadtree_builder.py:85-235`), but runs entirely in hand-written HIP kernels behind the C ABI of
 `libsttm_hip.so`.  PyTorch is used for device memory and the current stream only.
 """
+import ctypes
+import threading
+
 import torch
 
 from . import _lib
@@ -16,23 +19,87 @@ _ws_bytes_cache = {}    # (T, H, W, C, dtype, root_level) -> bytes
 
 
 _seq = [0]
+_seq_lock = threading.Lock()
+_stream_locks = {}          # (device, stream) -> lock: the scratch and the pinned counts of a stream serve ONE call at a time
 
 
-def _counts_host(device, stream_handle):
-    """Pinned landing pad of the label kernel's counts: one per (device, stream), so callers on different streams
+def _next_seq(n=1):
+    with _seq_lock:
+        first = (_seq[0] % 0x3fff0000) + 1
+        _seq[0] = first + n - 1
+    return first
+
+
+def _stream_guard(key):
+    """Two host threads must not issue merges on the SAME stream at the same time: they would share that stream's scratch
+    and pinned count buffer.  (Each thread on its own stream is fine -- see tests/test_hip_parity.py.)  Raises instead of racing."""
+    lock = _stream_locks.get(key)
+    if lock is None:
+        lock = _stream_locks.setdefault(key, threading.Lock())
+    if not lock.acquire(blocking=False):
+        raise RuntimeError("sttm_amd: another host thread is inside a merge call on this same stream; give every thread "
+                           "its own torch.cuda.Stream (the scratch and the pinned counts are per stream)")
+    return lock
+
+
+def _counts_host(device, stream_handle, rows=1):
+    """Pinned landing pad of the label stage's counts: one per (device, stream), so callers on different streams
     (e.g. two host threads) never share one."""
     key = (device, stream_handle)
     buf = _pinned_counts.get(key)
-    if buf is None:
-        buf = torch.zeros(_lib.CNT_SLOTS, dtype=torch.int32).pin_memory()
+    if buf is None or buf.shape[0] < rows:
+        buf = torch.zeros((max(rows, 16), _lib.CNT_SLOTS), dtype=torch.int32).pin_memory()
         _pinned_counts[key] = buf
     return buf
 
 
+def _channels_last(x):
+    """The production layout is a channels-last VIEW (stride_c == 1); anything else gets one transposing copy (enqueued on the
+    current stream, before the kernels that read it)."""
+    if x.stride(1) != 1 or (x.data_ptr() % 16) != 0:
+        x = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    return x
+
+
+def _workspace_bytes(lib, T, H, W, C, dtype, root_level):
+    key = (T, H, W, C, dtype, int(root_level))
+    nbytes = _ws_bytes_cache.get(key)
+    if nbytes is None:
+        nbytes = lib.sttm_quadtree_workspace_bytes(T, H, W, C, dtype, int(root_level))
+        if nbytes == 0:
+            code = lib.sttm_quadtree_num_levels(H, W, int(root_level))
+            _lib.raise_for(code if code < 0 else _lib.ERR_ARG)
+        _ws_bytes_cache[key] = nbytes
+    return nbytes
+
+
+def _scratch(dev, stream, nbytes, rows):
+    skey = (dev, stream.cuda_stream)               # scratch is reused call after call on the SAME stream (stream-ordered)
+    cached = _ws_cache.get(skey)
+    if cached is None or cached[0].numel() < nbytes or cached[1].shape[0] < rows:
+        cached = (torch.empty(nbytes, dtype=torch.uint8, device=dev),
+                  torch.empty((max(rows, 16), _lib.CNT_SLOTS), dtype=torch.int32, device=dev))
+        _ws_cache[skey] = cached
+    return cached
+
+
+def _wait(lib, host_row, seq, stream, counts_row):
+    # Output sizes are data dependent, so the host must learn N' -- but only N': the label stage publishes the counts into
+    # pinned memory and we wait on that, returning while the feature gather is still running.
+    if lib.sttm_wait_counts(host_row.data_ptr(), seq, 2_000_000) != 0:
+        host_row.copy_(counts_row, non_blocking=True)  # fallback: classic D2H + stream sync
+        stream.synchronize()
+    cnt = host_row.tolist()
+    if cnt[_lib.CNT_OVERFLOW]:
+        raise RuntimeError("libsttm_hip: internal list overflow (please report): counts=%s" % cnt)
+    return cnt
+
+
 def quadtree_merge_raw(x, threshold, temporal_thresh, root_level, weighted_avg, head_dim, slow_ver=False, return_ctx=False,
-                       feat_dest=None):
+                       feat_dest=None, events=None):
     """Launch the merge of one video and return the worst-case-sized outputs plus the host counts.
-    x: logical [T, C, H, W] CUDA tensor (any strides; channels-last views run zero-copy)."""
+    x: logical [T, C, H, W] CUDA tensor (any strides; channels-last views run zero-copy).
+    events: optional _lib.KernelEvents -- the library records them around its kernels (per-kernel timing)."""
     if not x.is_cuda:
         raise RuntimeError("sttm_amd runs on the GPU only: the input must be a CUDA (ROCm) tensor; "
                            "there is no CPU fallback")
@@ -42,57 +109,38 @@ def quadtree_merge_raw(x, threshold, temporal_thresh, root_level, weighted_avg, 
         raise NotImplementedError(f"dtype {x.dtype} is not supported (float32, bfloat16, float16)")
     lib = _lib.load()
     T, C, H, W = x.shape
-    if x.stride(1) != 1 or (x.data_ptr() % 16) != 0:
-        # not the production (channels-last view) layout: one transposing copy
-        x = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
     dev = x.device
     dtype = _DTYPE_CODE[x.dtype]
     head_dim = 0 if head_dim is None else int(head_dim)
-    key = (T, H, W, C, dtype, int(root_level))
-    nbytes = _ws_bytes_cache.get(key)
-    if nbytes is None:
-        nbytes = lib.sttm_quadtree_workspace_bytes(T, H, W, C, dtype, int(root_level))
-        if nbytes == 0:
-            code = lib.sttm_quadtree_num_levels(H, W, int(root_level))
-            _lib.raise_for(code if code < 0 else _lib.ERR_ARG)
-        _ws_bytes_cache[key] = nbytes
+    nbytes = _workspace_bytes(lib, T, H, W, C, dtype, root_level)
     N = T * H * W
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev)
-        skey = (dev, stream.cuda_stream)           # scratch is reused call after call on the SAME stream (stream-ordered)
-        cached = _ws_cache.get(skey)
-        if cached is None or cached[0].numel() < nbytes:
-            cached = (torch.empty(nbytes, dtype=torch.uint8, device=dev),
-                      torch.empty(_lib.CNT_SLOTS, dtype=torch.int32, device=dev))
-            _ws_cache[skey] = cached
-        ws, counts = cached
-        if feat_dest is None:
-            feat = torch.empty((N, C), dtype=x.dtype, device=dev)
-        else:
-            # caller-owned destination (fused slice -> merge -> concat): rows [0, N') of it receive the merged features
-            feat = feat_dest
-            if (feat.dim() != 2 or feat.size(1) != C or feat.dtype != x.dtype or feat.device != dev
-                    or not feat.is_contiguous() or feat.data_ptr() % 16):
-                raise ValueError("feat_dest must be a contiguous, 16-byte aligned [rows, C] tensor of the input's dtype and device")
-        npatch = torch.empty(N, dtype=torch.int32, device=dev)
-        tlbr = torch.empty((N, 5), dtype=torch.int32, device=dev)
-        host = _counts_host(dev, stream.cuda_stream)
-        _seq[0] = (_seq[0] % 0x3fffffff) + 1
-        seq = _seq[0]
-        rc = lib.sttm_quadtree_merge_async(
-            x.data_ptr(), x.stride(0), x.stride(1), x.stride(2), x.stride(3), T, C, H, W, dtype,
-            float(threshold), float(temporal_thresh), int(root_level), int(bool(weighted_avg)), head_dim,
-            int(bool(slow_ver)), ws.data_ptr(), ws.numel(), feat.data_ptr(), npatch.data_ptr(), tlbr.data_ptr(), counts.data_ptr(),
-            host.data_ptr(), seq, stream.cuda_stream)
-        _lib.raise_for(rc)
-        # Output sizes are data dependent, so the host must learn N' -- but only N': the label kernel publishes the
-        # counts into pinned memory and we spin on that, returning while the feature gather is still running.
-        if lib.sttm_wait_counts(host.data_ptr(), seq, 2_000_000) != 0:
-            host.copy_(counts, non_blocking=True)  # fallback: classic D2H + stream sync
-            stream.synchronize()
-    cnt = host.tolist()
-    if cnt[_lib.CNT_OVERFLOW]:
-        raise RuntimeError("libsttm_hip: internal list overflow (please report): counts=%s" % cnt)
+        guard = _stream_guard((dev, stream.cuda_stream))
+        try:
+            x = _channels_last(x)
+            ws, counts = _scratch(dev, stream, nbytes, 1)
+            if feat_dest is None:
+                feat = torch.empty((N, C), dtype=x.dtype, device=dev)
+            else:
+                # caller-owned destination (fused slice -> merge -> concat): rows [0, N') of it receive the merged features
+                feat = feat_dest
+                if (feat.dim() != 2 or feat.size(1) != C or feat.dtype != x.dtype or feat.device != dev
+                        or not feat.is_contiguous() or feat.data_ptr() % 16):
+                    raise ValueError("feat_dest must be a contiguous, 16-byte aligned [rows, C] tensor of the input's dtype and device")
+            npatch = torch.empty(N, dtype=torch.int32, device=dev)
+            tlbr = torch.empty((N, 5), dtype=torch.int32, device=dev)
+            host = _counts_host(dev, stream.cuda_stream)
+            seq = _next_seq()
+            rc = lib.sttm_quadtree_merge_async(
+                x.data_ptr(), x.stride(0), x.stride(1), x.stride(2), x.stride(3), T, C, H, W, dtype,
+                float(threshold), float(temporal_thresh), int(root_level), int(bool(weighted_avg)), head_dim,
+                int(bool(slow_ver)), ws.data_ptr(), ws.numel(), feat.data_ptr(), npatch.data_ptr(), tlbr.data_ptr(),
+                counts.data_ptr(), host.data_ptr(), seq, events.pointer() if events is not None else None, stream.cuda_stream)
+            _lib.raise_for(rc)
+            cnt = _wait(lib, host[0], seq, stream, counts[0])
+        finally:
+            guard.release()
     if return_ctx:
         return feat, npatch, tlbr, cnt, (x, ws, counts, dtype, stream)
     return feat, npatch, tlbr, cnt
@@ -105,8 +153,7 @@ def _apply_side_tensor(v, ctx, root_level, sum_mode):
     if v.dtype not in _DTYPE_CODE:
         raise NotImplementedError(f"dtype {v.dtype} is not supported")
     T, Cv, H, W = v.shape
-    if v.stride(1) != 1 or (v.data_ptr() % 16) != 0:
-        v = v.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    v = _channels_last(v)
     out = torch.empty((T * H * W, Cv), dtype=v.dtype, device=v.device)
     rc = lib.sttm_quadtree_apply(v.data_ptr(), v.stride(0), v.stride(1), v.stride(2), v.stride(3), T, Cv, H, W,
                                  _DTYPE_CODE[v.dtype], int(bool(sum_mode)), x.shape[1], dtype_feat, int(root_level),
@@ -115,21 +162,15 @@ def _apply_side_tensor(v, ctx, root_level, sum_mode):
     return out
 
 
-_side_streams = {}
-
-
-_BATCH_TIMING = []          # measurement hook (tools/batch_streams.py): non-empty list -> timestamps after the enqueue loop
-
-
 def get_quadtree_features_batch(videos, threshold, temporal_thresh=-1.0, root_level=0, weighted_avg=False,
-                                slow_ver=False, head_dim=None, n_streams=3):
+                                slow_ver=False, head_dim=None, events=None):
     """Extension (not in the reference, whose API is one video per call): merge a LIST of videos and return the list of
     (features, num_patches, tlbr) triples -- results identical to calling get_quadtree_features on each.
 
-    Videos are independent, so consecutive videos are issued round-robin on `n_streams` side streams: the latency-bound
-    label kernel of one video (16 workgroups) overlaps the bandwidth-bound kernels of the next.  The host waits for the
-    per-video token counts only after everything has been enqueued; the caller's current stream is made to wait for the
-    side streams, so downstream ops stay stream-ordered."""
+    Videos of one shape / dtype / stride set go through sttm_quadtree_merge_batch together: every kernel gets a second grid
+    dimension over the videos, so the launch ramps and tails and the latency-bound label stage of one video overlap the
+    bandwidth-bound kernels of its neighbours -- on the caller's own stream, with no side streams.  The host waits for the
+    per-video token counts only after everything has been enqueued."""
     if not videos:
         return []
     lib = _lib.load()
@@ -138,78 +179,55 @@ def get_quadtree_features_batch(videos, threshold, temporal_thresh=-1.0, root_le
         raise RuntimeError("sttm_amd runs on the GPU only: every video must be a CUDA (ROCm) tensor on one device; "
                            "there is no CPU fallback")
     head = 0 if head_dim is None else int(head_dim)
-    streams = _side_streams.setdefault((dev, n_streams), None)
+    out = [None] * len(videos)
     with torch.cuda.device(dev):
-        if streams is None:
-            streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
-            _side_streams[(dev, n_streams)] = streams
-        cur = torch.cuda.current_stream(dev)
-        ready = torch.cuda.Event()
-        ready.record(cur)
-        pend = []
-        hosts = _pinned_counts.get((dev, "batch"))
-        if hosts is None or hosts.shape[0] < len(videos):
-            hosts = torch.zeros((max(64, len(videos)), _lib.CNT_SLOTS), dtype=torch.int32).pin_memory()
-            _pinned_counts[(dev, "batch")] = hosts
-        for j, x in enumerate(videos):
-            if x.dim() != 4 or x.dtype not in _DTYPE_CODE:
-                raise ValueError("expected [T, C, H, W] float32 / bfloat16 / float16 tensors")
-            if x.stride(1) != 1 or (x.data_ptr() % 16) != 0:
-                x = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
-            T, C, H, W = x.shape
-            dtype = _DTYPE_CODE[x.dtype]
-            key = (T, H, W, C, dtype, int(root_level))
-            nbytes = _ws_bytes_cache.get(key)
-            if nbytes is None:
-                nbytes = lib.sttm_quadtree_workspace_bytes(T, H, W, C, dtype, int(root_level))
-                if nbytes == 0:
-                    code = lib.sttm_quadtree_num_levels(H, W, int(root_level))
-                    _lib.raise_for(code if code < 0 else _lib.ERR_ARG)
-                _ws_bytes_cache[key] = nbytes
-            st = streams[j % n_streams]
-            if j < n_streams:
-                st.wait_event(ready)                       # inputs were produced on the caller's stream
-            skey = (dev, st.cuda_stream)
-            cached = _ws_cache.get(skey)
-            if cached is None or cached[0].numel() < nbytes:
-                cached = (torch.empty(nbytes, dtype=torch.uint8, device=dev),
-                          torch.empty(_lib.CNT_SLOTS, dtype=torch.int32, device=dev))
-                for t_ in cached:                      # allocated on the caller's stream, used on the side stream
-                    t_.record_stream(st)
-                _ws_cache[skey] = cached
-            ws, counts = cached
-            N = T * H * W
-            feat = torch.empty((N, C), dtype=x.dtype, device=dev)
-            npatch = torch.empty(N, dtype=torch.int32, device=dev)
-            tlbr = torch.empty((N, 5), dtype=torch.int32, device=dev)
-            for t_ in (feat, npatch, tlbr):
-                t_.record_stream(st)
-            _seq[0] = (_seq[0] % 0x3fffffff) + 1
-            seq = _seq[0]
-            rc = lib.sttm_quadtree_merge_async(
-                x.data_ptr(), x.stride(0), x.stride(1), x.stride(2), x.stride(3), T, C, H, W, dtype,
-                float(threshold), float(temporal_thresh), int(root_level), int(bool(weighted_avg)), head, int(bool(slow_ver)),
-                ws.data_ptr(), ws.numel(), feat.data_ptr(), npatch.data_ptr(), tlbr.data_ptr(), counts.data_ptr(),
-                hosts[j].data_ptr(), seq, st.cuda_stream)
-            _lib.raise_for(rc)
-            pend.append((feat, npatch, tlbr, seq, st, counts))
-        if _BATCH_TIMING:
-            import time as _t
-            _BATCH_TIMING.append(_t.perf_counter())
-        out = []
-        for j, (feat, npatch, tlbr, seq, st, counts) in enumerate(pend):
-            if lib.sttm_wait_counts(hosts[j].data_ptr(), seq, 2_000_000) != 0:
-                st.synchronize()
-                raise RuntimeError("libsttm_hip: the token counts of a batched merge did not arrive")
-            cnt = hosts[j].tolist()
-            if cnt[_lib.CNT_OVERFLOW]:
-                raise RuntimeError("libsttm_hip: internal list overflow (please report): counts=%s" % cnt)
-            n = cnt[_lib.CNT_OUT]
-            out.append((feat[:n], npatch[:n], tlbr[:n]))
-        for st in streams:
-            done = torch.cuda.Event()
-            done.record(st)
-            cur.wait_event(done)
+        stream = torch.cuda.current_stream(dev)
+        guard = _stream_guard((dev, stream.cuda_stream))
+        try:
+            groups = {}
+            vids = []
+            for j, x in enumerate(videos):
+                if x.dim() != 4 or x.dtype not in _DTYPE_CODE:
+                    raise ValueError("expected [T, C, H, W] float32 / bfloat16 / float16 tensors")
+                x = _channels_last(x)
+                vids.append(x)
+                groups.setdefault((tuple(x.shape), x.dtype, tuple(x.stride())), []).append(j)
+            pend = []
+            rows_used = 0
+            total = len(videos)
+            host = _counts_host(dev, stream.cuda_stream, total)
+            # one workspace block per video of the call (all groups): sized for the largest
+            per_video = 0
+            for (shape, dt, _), ids in groups.items():
+                T, C, H, W = shape
+                per_video = max(per_video, _workspace_bytes(lib, T, H, W, C, _DTYPE_CODE[dt], root_level))
+            per_video = (per_video + 255) // 256 * 256
+            ws, counts = _scratch(dev, stream, per_video * total, total)
+            for (shape, dt, strides), ids in groups.items():
+                T, C, H, W = shape
+                N = T * H * W
+                n = len(ids)
+                feats = [torch.empty((N, C), dtype=dt, device=dev) for _ in ids]
+                npatches = [torch.empty(N, dtype=torch.int32, device=dev) for _ in ids]
+                tlbrs = [torch.empty((N, 5), dtype=torch.int32, device=dev) for _ in ids]
+                arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])      # noqa: E731
+                seq = _next_seq(n)
+                rc = lib.sttm_quadtree_merge_batch(
+                    n, arr([vids[j] for j in ids]), strides[0], strides[1], strides[2], strides[3], T, C, H, W, _DTYPE_CODE[dt],
+                    float(threshold), float(temporal_thresh), int(root_level), int(bool(weighted_avg)), head, int(bool(slow_ver)),
+                    ws.data_ptr() + rows_used * per_video, per_video, arr(feats), arr(npatches), arr(tlbrs),
+                    counts[rows_used].data_ptr(), host[rows_used].data_ptr(), seq,
+                    events.pointer() if events is not None else None, stream.cuda_stream)
+                _lib.raise_for(rc)
+                for k, j in enumerate(ids):
+                    pend.append((j, feats[k], npatches[k], tlbrs[k], seq + k, rows_used + k))
+                rows_used += n
+            for j, feat, npatch, tlbr, seq, row in pend:
+                cnt = _wait(lib, host[row], seq, stream, counts[row])
+                n_out = cnt[_lib.CNT_OUT]
+                out[j] = (feat[:n_out], npatch[:n_out], tlbr[:n_out])
+        finally:
+            guard.release()
     return out
 
 

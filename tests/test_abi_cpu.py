@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"libsttm_hip.so does not export {n}"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
-    assert lib.sttm_abi_version() == 3
+    assert lib.sttm_abi_version() == _lib.ABI_VERSION == 4
 
 
 @pytest.mark.parametrize("H,W", [(14, 14), (27, 27), (20, 36), (18, 26), (13, 24), (16, 22), (10, 30), (7, 7),
@@ -120,3 +120,19 @@ def test_host_side_size_functions_of_the_baselines():
     assert lib.sttm_dycoke_out_rows(5, 49, 24) == 2 * 49 + 3 * 24
     # octree: root level outside [2, ..., side] -> no workspace (the wrapper raises IndexError)
     assert lib.sttm_octree_workspace_bytes(1, 14, 32, 0, 9) == 0 and lib.sttm_octree_workspace_bytes(1, 14, 32, 0, 0) > 0
+
+
+def test_configure_accepts_known_keys_only():
+    lib = _lib.load()
+    assert lib.sttm_configure(b"no_fold", 0) == 0 and lib.sttm_configure(b"fold_kb", 20) == 0
+    assert lib.sttm_configure(b"does_not_exist", 1) == _lib.ERR_ARG
+    assert "does_not_exist" in _lib.last_error()
+
+
+def test_product_library_has_no_measurement_hooks():
+    """wall-clock stamps / ablation modes exist only in the -DSTTM_DEV build (libsttm_hip_dev.so), never in the product library."""
+    lib = _lib.load()
+    assert not hasattr(lib, "sttm_dev_hooks")
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sttm_amd", "csrc", "api.hip")).read()
+    body = src[src.index("int merge_group("):src.index("}  // namespace\n\nextern")]
+    assert "getenv" not in body          # tuning switches are read once (config()), never per call

@@ -155,11 +155,80 @@ def test_slow_ver_against_oracle(T, C, H, W, seed, kind):
     _check(out, exp, FP32_TOL, f"slow_ver+head {kind}")
 
 
+LABEL_PATHS = [
+    dict(no_fold=1),                                 # stand-alone fused label kernel (in-kernel grid barrier)
+    dict(no_fold=1, no_fuse=1),                      # stand-alone label stage as two launches (probe, final)
+    dict(force_gmem_labels=1),                       # folded into the pair kernel, column arrays in global scratch
+    dict(no_fold=1, force_gmem_labels=1),            # stand-alone, global scratch (the path of columns too large for LDS)
+    dict(no_fold=1, no_fuse=1, force_gmem_labels=1),
+    dict(fold_kb=5),                                 # folded with a tiny LDS budget: busy columns overflow to global scratch in-kernel
+]
+
+
+@pytest.mark.parametrize("opts", LABEL_PATHS, ids=lambda o: "+".join(f"{k}={v}" for k, v in o.items()))
+def test_label_stage_paths_give_identical_results(opts):
+    """Every way the label stage can run (sttm_configure switches; none changes results) against the oracle: Q2-sensitive golden
+    cases, a 128-frame clip whose busy columns exceed a small LDS budget, a deep tree, a long clip."""
+    from oracle import sttm_oracle as O
+    from sttm_amd import _lib, get_quadtree_features
+    from sttm_amd.synth import synth_video
+    defaults = dict(no_fold=0, no_fuse=0, force_gmem_labels=0, fold_kb=20)
+    try:
+        _lib.configure(**opts)
+        for path in case_paths(["st_"]):
+            c = load_case(path)
+            thr, kw = quadtree_kwargs(c["meta"])
+            if thr >= 1.0 or "pos_embs" in c:
+                continue
+            out = get_quadtree_features(c["x"].to(_dev()), thr, **kw)
+            _check(out, (c["feat"], c["npatch"], c["tlbr"]), FP32_TOL if c["x"].dtype == torch.float32 else BF16_TOL, c["name"])
+        for (T, C, H, W, seed, thr, tthr, root, kind) in [(128, 64, 14, 14, 201, 0.85, 0.55, 1, "synth"), (128, 64, 14, 14, 202, 0.80, 0.50, 1, "smooth"),
+                                                          (24, 64, 20, 36, 203, 0.85, 0.60, 0, "synth"), (400, 32, 14, 14, 204, 0.85, 0.55, 1, "smooth")]:
+            kwv = dict(c=0.15, p_static=0.7) if kind == "smooth" else {}
+            x = synth_video(T, C, H, W, seed=seed, **kwv)
+            exp = O.get_quadtree_features(x, thr, tthr, root)
+            out = get_quadtree_features(x.to(_dev()), thr, tthr, root)
+            _check(out, exp, FP32_TOL, f"{opts} T={T} {H}x{W} {kind}")
+    finally:
+        _lib.configure(**defaults)
+
+
+def test_same_stream_from_two_threads_is_refused_not_raced():
+    """The scratch and the pinned counts are per stream: a second host thread entering a merge on the SAME stream while another
+    is inside gets a RuntimeError instead of sharing them."""
+    import threading
+    from sttm_amd import get_quadtree_features, quadtree_interface as QI
+    from sttm_amd.synth import synth_video
+    dev = _dev()
+    x = synth_video(8, 64, 14, 14, seed=3).to(dev)
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    get_quadtree_features(x, 0.85, 0.55, 1)
+    lock = QI._stream_guard(key)                 # stand-in for "another thread is inside the call"
+    errs = []
+
+    def other():
+        try:
+            with torch.cuda.stream(torch.cuda.current_stream(dev)):
+                get_quadtree_features(x, 0.85, 0.55, 1)
+        except RuntimeError as e:
+            errs.append(str(e))
+    try:
+        th = threading.Thread(target=other)
+        th.start(); th.join()
+    finally:
+        lock.release()
+    assert errs and "same stream" in errs[0]
+    get_quadtree_features(x, 0.85, 0.55, 1)      # and the stream is usable again
+
+
 def test_batched_extension_equals_per_video_calls():
-    """get_quadtree_features_batch (two side streams) returns exactly what per-video calls return."""
+    """get_quadtree_features_batch (sttm_quadtree_merge_batch: same-shaped videos share one set of launches) returns exactly what
+    per-video calls return; mixed shapes are grouped, more than STTM_BATCH_MAX videos of a shape are issued in groups."""
     from sttm_amd import get_quadtree_features, get_quadtree_features_batch
     from sttm_amd.synth import synth_video
-    vids = [synth_video(T, 1024, 14, 14, seed=90 + i).to(_dev()) for i, T in enumerate([16, 8, 16, 12, 16, 16, 4])]
+    vids = [synth_video(T, 256, 14, 14, seed=90 + i).to(_dev()) for i, T in enumerate([16, 8, 16, 12, 16, 16, 4] + [16] * 18)]
+    vids.append(synth_video(6, 256, 20, 36, seed=77).to(_dev()))
+    vids.append(synth_video(16, 256, 14, 14, seed=78, dtype=torch.bfloat16).to(_dev()))
     single = [get_quadtree_features(v, 0.85, 0.55, 1) for v in vids]
     for rep in range(3):
         batch = get_quadtree_features_batch(vids, 0.85, 0.55, 1)

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from sttm_amd.distributed import gather_counts, shard_videos
+from sttm_amd.distributed import gather_counts, gather_indices, shard_videos
 
 
 def _free_port():
@@ -27,14 +27,17 @@ def _worker(rank, world, port, n_videos, out_dir):
     from oracle import sttm_oracle as O
     from sttm_amd.synth import synth_video
     ids = shard_videos(n_videos, world, rank)
-    counts = []
+    counts, indices = [], []
     for v in ids:
         x = synth_video(3, 16, 14, 14, seed=v)
-        f, _, _ = O.get_quadtree_features(x, 0.85, 0.55, 1)
+        f, _, t = O.get_quadtree_features(x, 0.85, 0.55, 1)
         counts.append(f.shape[0])
+        indices.append(t[:, 0] * 196 + t[:, 1] * 14 + t[:, 2])
     full = gather_counts(ids, counts, n_videos, torch.device("cpu"), dist)
+    idx = gather_indices(ids, indices, n_videos, 3 * 196, torch.device("cpu"), dist)
     dist.barrier()
     torch.save(full, os.path.join(out_dir, f"r{rank}.pt"))
+    torch.save(idx, os.path.join(out_dir, f"i{rank}.pt"))
     dist.destroy_process_group()
 
 
@@ -43,11 +46,16 @@ def test_two_rank_sharding_matches_single_process(tmp_path):
     mp.spawn(_worker, args=(world, _free_port(), n_videos, str(tmp_path)), nprocs=world, join=True)
     from oracle import sttm_oracle as O
     from sttm_amd.synth import synth_video
-    expect = torch.tensor([O.get_quadtree_features(synth_video(3, 16, 14, 14, seed=v), 0.85, 0.55, 1)[0].shape[0]
-                           for v in range(n_videos)], dtype=torch.int32)
+    outs = [O.get_quadtree_features(synth_video(3, 16, 14, 14, seed=v), 0.85, 0.55, 1) for v in range(n_videos)]
+    expect = torch.tensor([o[0].shape[0] for o in outs], dtype=torch.int32)
+    expect_idx = torch.full((n_videos, 3 * 196), -1, dtype=torch.int32)
+    for v, (_, _, t) in enumerate(outs):
+        expect_idx[v, :t.shape[0]] = t[:, 0] * 196 + t[:, 1] * 14 + t[:, 2]
     for r in range(world):
         got = torch.load(os.path.join(str(tmp_path), f"r{r}.pt"))
         assert torch.equal(got, expect)
+        # the padded index gather of the validation mode: every rank holds every video's merged-token indices
+        assert torch.equal(torch.load(os.path.join(str(tmp_path), f"i{r}.pt")), expect_idx)
 
 
 def test_shard_videos_partitions():

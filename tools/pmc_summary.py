@@ -12,8 +12,8 @@ import re
 import sqlite3
 import sys
 
-NAMES = {"k_spatial": "quadtree_spatial", "k_pairs": "temporal_pairs", "k_col_labels": "labels_scan",
-         "k_rank": "labels_scan", "k_group_mean": "group_mean", "k_slow_filter": "temporal_pairs"}
+NAMES = {"k_spatial": "quadtree_spatial", "k_pairs": "temporal_pairs_labels", "k_col_labels": "labels_standalone",
+         "k_group_mean": "group_mean", "k_slow_filter": "temporal_pairs_labels"}
 
 
 def per_kernel(db, counter):
@@ -39,7 +39,10 @@ def main():
         rows.append((k, f.get(k, [("", 0, 0)])[0][1], fk, fetch_b / 1e6, write_b / 1e6))
         g = NAMES.get(k, k)
         agg[g] = agg.get(g, 0) + fetch_b + write_b
-    rec = {"workload": "T128_14x14x1024_f32_sttm_0.85_0.55", "tag": tag,
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from sttm_amd import _lib
+    rec = {"workload": "T128_14x14x1024_f32_sttm_0.85_0.55", "tag": tag, "build_tag": _lib.build_tag(),
+           "hbm_bytes_per_video": round(sum(agg.values())),
            "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes, --kernel-include-regex sttm, "
                      "bench.py --steps 2 --warmup 1; mean per launch; fetch = 2 * FETCH_SIZE KB (gfx950 correction), write = WRITE_SIZE KB",
            "hbm_bytes_per_launch": {k: round(v) for k, v in agg.items()}}
