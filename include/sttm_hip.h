@@ -142,12 +142,12 @@ int sttm_quadtree_merge_batch(int n_videos, const void* const* x, int64_t stride
  * Tuning and test switches (process-wide; none of them changes results).  Defaults come from the environment variable
  * STTM_<KEY> read once at first use; sttm_configure overrides a key at run time (call it while no merge is being issued from
  * another thread).  Returns STTM_ERR_ARG for an unknown key.  Keys:
- *   "pairs_seg"   frames per XCD-local run of the pair kernel's workgroup map (default 16; 0 = plain order)
- *   "pairs_nt"    pair-kernel block size (64 / 128 / 256)
+ *   "pairs_seg"   consecutive frame pairs of one root cell per pair workgroup (0 = automatic: about one workgroup per CU)
+ *   "pairs_nt"    pair-kernel block size (0 = automatic: 128 threads per frame pair of the run, 256 .. 1024)
  *   "gm_split"    group-mean workgroups per frame (0 = automatic)
  *   "label_nt"    threads per column of the stand-alone label kernels (256 / 512 / 1024)
  *   "vec16" / "vec32"   force the pack width of 16-bit / 32-bit inputs in the spatial kernel (0 = automatic)
- *   "fold_kb"     LDS budget (KB) per pair workgroup when the label stage runs inside the pair kernel (default 20)
+ *   "fold_kb"     LDS budget (KB) per pair workgroup when the label stage runs inside the pair kernel (default 64)
  *   "no_fold"     1: never run the label stage inside the pair kernel (stand-alone label kernel instead)
  *   "no_fuse"     1: stand-alone label stage as two launches (no in-kernel grid barrier)
  *   "force_gmem_labels"  1: label stage on global scratch instead of LDS (the path of columns too large for LDS)
@@ -176,7 +176,10 @@ int sttm_merge_dst_idx(const int32_t* pairs, int L, int N, int32_t* rep_out, voi
 
 /* ------------------------------------------------------------------------------------------------
  * ToMe baseline: ONE iteration of tome_per_video's loop (tome_token_merger.py:143-149), i.e.
- * bipartite_soft_matching (:13-57) + merge_wavg (:77-91) on a [n, C] token matrix.  float32 only.
+ * bipartite_soft_matching (:13-57) + merge_wavg (:77-91) on a [n, C] token matrix.  dtype float32 (exact fp32 products on the
+ * fp32-input MFMA), bfloat16 or float16 (every intermediate rounded to the input dtype like the reference's torch ops on
+ * 16-bit hidden states; bf16 / f16 MFMA; x_out has the input dtype, size / size_out stay float32 arrays holding
+ * dtype-representable values).
  *
  *   x          [n, C] row-major tokens          size  [n] token sizes, or NULL for all ones (first iteration)
  *   idx        [n] int64 token ids              r     tokens to remove, 1 <= r <= n / 2 (callers clamp like :26)
@@ -214,7 +217,8 @@ int sttm_pool2d(const void* x, int T, int H, int W, int C, int dtype, int mode, 
 int sttm_resize_nearest(const void* x, int T, int H, int W, int C, int dtype, int OH, int OW, void* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * DyCoke stage-1 pruning: replaces dycoke_ttm (token_merging_utils/dycoke_merger.py:8-83).  float32 only.
+ * DyCoke stage-1 pruning: replaces dycoke_ttm (token_merging_utils/dycoke_merger.py:8-83).  float32, bfloat16, float16
+ * (16-bit inputs: the cosine follows the reference's per-op rounding to the input dtype).
  *   x [T*P, C] row-major tokens (P tokens per frame), k = int((1 - prune_ratio) * P) tokens kept per pruned frame.
  *   Pass 1: frames (2j, 2j+1) -- frame 2j+1 keeps its k least similar tokens (per-token cosine, ascending order).
  *   Pass 2: frames (4j, 4j+2), 4j < T-4 -- frame 4j+2 keeps its k least similar tokens w.r.t. frame 4j.

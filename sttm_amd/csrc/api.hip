@@ -33,13 +33,13 @@ int env_int(const char* name, int dflt) {
 Config& config() {
     static Config c = [] {
         Config d;
-        d.pairs_seg = env_int("STTM_PAIRS_SEG", 16);
-        d.pairs_nt = env_int("STTM_PAIRS_NT", 256);
+        d.pairs_seg = env_int("STTM_PAIRS_SEG", 0);
+        d.pairs_nt = env_int("STTM_PAIRS_NT", 0);
         d.gm_split = env_int("STTM_GM_SPLIT", 0);
         d.label_nt = env_int("STTM_LABEL_NT", 1024);
         d.vec16 = env_int("STTM_VEC16", 0);
         d.vec32 = env_int("STTM_VEC32", 0);
-        d.fold_kb = env_int("STTM_FOLD_KB", 20);
+        d.fold_kb = env_int("STTM_FOLD_KB", 64);
         d.no_fold = env_int("STTM_NO_FOLD", 0);
         d.no_fuse = env_int("STTM_NO_FUSE", env_int("STTM_NO_FUSE_LABELS", 0));
         d.force_gmem_labels = env_int("STTM_FORCE_GMEM_LABELS", 0);
@@ -372,9 +372,7 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
     ta.T = T; ta.H = H; ta.W = W; ta.C = C; ta.R = p.R;
     ta.dims = p.dims;
     ta.dtype = dtype; ta.vec = row_vec(C, dtype, vec, dense, all_bits % 32 == 0, head_dim);
-    ta.pairs_seg = cfg.pairs_seg >= 0 ? cfg.pairs_seg : 16;
-    if (ta.pairs_seg > T - 1) ta.pairs_seg = T - 1 > 0 ? T - 1 : 0;
-    ta.pairs_nt = (cfg.pairs_nt == 64 || cfg.pairs_nt == 128) ? cfg.pairs_nt : 256;
+    sttm::pairs_shape(T, p.R, nv, cfg.pairs_seg, cfg.pairs_nt, &ta.pairs_seg, &ta.pairs_nt);
     ta.label_nt = (cfg.label_nt == 256 || cfg.label_nt == 512) ? cfg.label_nt : 1024;
     ta.temporal_thresh = temporal_thresh;
     ta.weighted_avg = weighted_avg ? 1 : 0;
@@ -386,7 +384,7 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
     ta.force_gmem = cfg.force_gmem_labels ? 1 : 0;
     ta.no_fuse = cfg.no_fuse ? 1 : 0;
     ta.no_fold = cfg.no_fold ? 1 : 0;
-    ta.fold_kb = cfg.fold_kb > 0 ? cfg.fold_kb : 20;
+    ta.fold_kb = cfg.fold_kb > 0 ? cfg.fold_kb : 64;
     ta.S = b.S; ta.xrows = dense ? x[0] : nullptr; ta.meta = b.meta; ta.inrm = b.inrm; ta.rc_list = b.rc_list; ta.rc_stride = p.rc_stride;
     ta.edges = b.edges; ta.edge_sim = slow_ver ? b.edge_sim : nullptr; ta.ecap = p.ecap; ta.edge_cnt = b.edge_cnt; ta.cand_cnt = b.cand_cnt;
     ta.ecap_magic = 0xffffffffu / (unsigned)p.ecap + 1u;
@@ -663,15 +661,15 @@ int sttm_dycoke_ttm(const void* x, int T, int P, int C, int dtype, int k, void* 
                     void* out, int64_t* out_idx, void* stream_) {
     if (!x || !workspace || !out || !out_idx || P < 1 || C < 1 || k < 0 || k > P) return fail(STTM_ERR_ARG, "bad pointer or shape");
     if (T < 5) return fail(STTM_ERR_ARG, "stack expects a non-empty TensorList (dycoke_ttm needs at least 5 frames)");
-    if (dtype != STTM_F32) return fail(STTM_ERR_UNSUPPORTED, "dycoke_ttm runs in float32 only");
+    if (dtype < 0 || dtype > 2) return fail(STTM_ERR_ARG, "bad dtype");
+    if (dtype != STTM_F32 && (C & 1)) return fail(STTM_ERR_UNSUPPORTED, "16-bit inputs need an even channel count");
     if (P > 2048) return fail(STTM_ERR_UNSUPPORTED, "more than 2048 tokens per frame");
     if (workspace_bytes < sttm_dycoke_workspace_bytes(T, P, k)) return fail(STTM_ERR_ARG, "workspace too small");
     const size_t np = (size_t)dycoke_pairs(T);
     char* ws = reinterpret_cast<char*>(workspace);
     float* sim = reinterpret_cast<float*>(ws);
     int32_t* keep = reinterpret_cast<int32_t*>(ws + ((np * P * 4 + 255) / 256) * 256);
-    hipError_t e = sttm::launch_dycoke(reinterpret_cast<const float*>(x), T, P, C, k, sim, keep, reinterpret_cast<float*>(out), out_idx,
-                                       reinterpret_cast<hipStream_t>(stream_));
+    hipError_t e = sttm::launch_dycoke(x, T, P, C, dtype, k, sim, keep, out, out_idx, reinterpret_cast<hipStream_t>(stream_));
     if (e != hipSuccess) return fail(STTM_ERR_LAUNCH, "dycoke kernels: %s", hipGetErrorString(e));
     return STTM_OK;
 }

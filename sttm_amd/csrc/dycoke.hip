@@ -8,7 +8,8 @@
 //
 // Every output size is known in advance (k = int((1 - prune_ratio) * P) per pruned frame), so the three kernels are enqueued
 // with no host synchronisation:
-//   k_dycoke_sim     one wave per (frame pair, token): F.cosine_similarity's normalise-then-dot form, float32
+//   k_dycoke_sim     one wave per (frame pair, token): F.cosine_similarity's normalise-then-dot form (float32; k_dycoke_sim16
+//                    for bfloat16 / float16 with the per-op rounding of the input dtype)
 //   k_dycoke_select  one workgroup per frame pair: bitonic sort of (similarity, token) ascending in LDS, first k tokens
 //   k_dycoke_gather  one wave per output row: copies the row, writes its token id
 // HBM-bound: the similarity kernel reads every frame once for pass 1 and half of them again for pass 2.
@@ -79,6 +80,64 @@ __global__ void __launch_bounds__(256) k_dycoke_sim(DycokeArgs a) {
     }
 }
 
+// 16-bit inputs (bfloat16 / float16 hidden states): F.cosine_similarity runs on the input dtype, i.e. every intermediate tensor
+// is rounded to it (checked against the ATen CPU result, tests/golden/make_golden_dycoke16.py): |a| = round(sqrt(sum a^2)),
+// a / max(|a|, eps) rounded, the products rounded, their fp32 sum rounded.  One wave per (frame pair, token); the row is
+// read twice (norms, then the dot), the second time from cache.
+template <typename T> __device__ __forceinline__ float dyc_round(float f);
+template <> __device__ __forceinline__ float dyc_round<bf16_t>(float f) { return bf16_bits_to_float(float_to_bf16_bits(f)); }
+template <> __device__ __forceinline__ float dyc_round<f16_t>(float f) { return f16_bits_to_float(float_to_f16_bits(f)); }
+template <typename T> __device__ __forceinline__ float dyc_cvt(uint32_t bits16);
+template <> __device__ __forceinline__ float dyc_cvt<bf16_t>(uint32_t b) { return bf16_bits_to_float(b); }
+template <> __device__ __forceinline__ float dyc_cvt<f16_t>(uint32_t b) { return f16_bits_to_float(b); }
+
+template <typename T, bool VEC8>
+__global__ void __launch_bounds__(256) k_dycoke_sim16(DycokeArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    const int64_t total = (int64_t)(a.n1 + a.n2) * a.P;
+    const uint16_t* x = reinterpret_cast<const uint16_t*>(a.x);
+    for (int64_t w = (int64_t)blockIdx.x * nwave + wave; w < total; w += (int64_t)gridDim.x * nwave) {
+        const int j = (int)(w / a.P), p = (int)(w - (int64_t)j * a.P);
+        int fa, fb;
+        dycoke_pair(a, j, fa, fb);
+        const uint16_t* ra = x + ((int64_t)fa * a.P + p) * a.C;
+        const uint16_t* rb = x + ((int64_t)fb * a.P + p) * a.C;
+        float sa = 0.f, sb = 0.f, d = 0.f;
+        if constexpr (VEC8) {
+            for (int c = lane * 8; c < a.C; c += 512) {
+                const uint4 u = *reinterpret_cast<const uint4*>(ra + c), v = *reinterpret_cast<const uint4*>(rb + c);
+                const uint32_t uw[4] = {u.x, u.y, u.z, u.w}, vw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float u0 = dyc_cvt<T>(uw[i] & 0xffffu), u1 = dyc_cvt<T>(uw[i] >> 16);
+                    const float v0 = dyc_cvt<T>(vw[i] & 0xffffu), v1 = dyc_cvt<T>(vw[i] >> 16);
+                    sa = fmaf(u0, u0, sa); sa = fmaf(u1, u1, sa); sb = fmaf(v0, v0, sb); sb = fmaf(v1, v1, sb);
+                }
+            }
+        } else {
+            for (int c = lane; c < a.C; c += 64) { const float u = dyc_cvt<T>(ra[c]), v = dyc_cvt<T>(rb[c]); sa = fmaf(u, u, sa); sb = fmaf(v, v, sb); }
+        }
+        sa = wave_sum(sa); sb = wave_sum(sb);
+        const float na = fmaxf(dyc_round<T>(sqrtf(sa)), 1e-8f), nb = fmaxf(dyc_round<T>(sqrtf(sb)), 1e-8f);
+        auto term = [&](float u, float v) { return dyc_round<T>(dyc_round<T>(u / na) * dyc_round<T>(v / nb)); };
+        if constexpr (VEC8) {
+            for (int c = lane * 8; c < a.C; c += 512) {
+                const uint4 u = *reinterpret_cast<const uint4*>(ra + c), v = *reinterpret_cast<const uint4*>(rb + c);
+                const uint32_t uw[4] = {u.x, u.y, u.z, u.w}, vw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    d += term(dyc_cvt<T>(uw[i] & 0xffffu), dyc_cvt<T>(vw[i] & 0xffffu));
+                    d += term(dyc_cvt<T>(uw[i] >> 16), dyc_cvt<T>(vw[i] >> 16));
+                }
+            }
+        } else {
+            for (int c = lane; c < a.C; c += 64) d += term(dyc_cvt<T>(ra[c]), dyc_cvt<T>(rb[c]));
+        }
+        d = wave_sum(d);
+        if (lane == 0) a.sim[w] = dyc_round<T>(d);
+    }
+}
+
 __global__ void __launch_bounds__(1024) k_dycoke_select(DycokeArgs a, int npad) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* key = reinterpret_cast<float*>(smem_raw);
@@ -141,22 +200,33 @@ __global__ void __launch_bounds__(256) k_dycoke_gather(DycokeArgs a, int split) 
     }
 }
 
-hipError_t launch_dycoke(const float* x, int T, int P, int C, int k, float* sim, int32_t* keep, float* out, int64_t* out_idx,
+hipError_t launch_dycoke(const void* x, int T, int P, int C, int dtype, int k, float* sim, int32_t* keep, void* out, int64_t* out_idx,
                          hipStream_t stream) {
     DycokeArgs a;
-    a.x = x; a.T = T; a.P = P; a.C = C; a.k = k;
+    a.x = reinterpret_cast<const float*>(x); a.T = T; a.P = P; a.C = C; a.k = k;
     a.n1 = T / 2;
     a.n2 = T > 4 ? (T - 4 + 3) / 4 : 0;
-    a.sim = sim; a.keep = keep; a.out = out; a.out_idx = out_idx;
+    a.sim = sim; a.keep = keep; a.out = reinterpret_cast<float*>(out); a.out_idx = out_idx;
     const int np = a.n1 + a.n2;
     if (np > 0) {
         int64_t blocks = ((int64_t)np * P + 3) / 4;
         if (blocks > 16384) blocks = 16384;
-        const bool vec_ok = (C % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
-        if (vec_ok && C <= 1024) hipLaunchKernelGGL(k_dycoke_sim<4>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
-        else if (vec_ok && C <= 2048) hipLaunchKernelGGL(k_dycoke_sim<8>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
-        else if (vec_ok && C <= 4096) hipLaunchKernelGGL(k_dycoke_sim<16>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL(k_dycoke_sim<0>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+        if (dtype == STTM_F32) {
+            const bool vec_ok = (C % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
+            if (vec_ok && C <= 1024) hipLaunchKernelGGL(k_dycoke_sim<4>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+            else if (vec_ok && C <= 2048) hipLaunchKernelGGL(k_dycoke_sim<8>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+            else if (vec_ok && C <= 4096) hipLaunchKernelGGL(k_dycoke_sim<16>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL(k_dycoke_sim<0>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+        } else {
+            const bool v8 = (C % 8 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
+            if (dtype == STTM_BF16) {
+                if (v8) hipLaunchKernelGGL((k_dycoke_sim16<bf16_t, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+                else hipLaunchKernelGGL((k_dycoke_sim16<bf16_t, false>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+            } else {
+                if (v8) hipLaunchKernelGGL((k_dycoke_sim16<f16_t, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+                else hipLaunchKernelGGL((k_dycoke_sim16<f16_t, false>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+            }
+        }
         if (k > 0) {
             int npad = 1;
             while (npad < P) npad <<= 1;
@@ -164,14 +234,17 @@ hipError_t launch_dycoke(const float* x, int T, int P, int C, int k, float* sim,
             hipLaunchKernelGGL(k_dycoke_select, dim3(np), dim3(nt), (size_t)npad * 8, stream, a, npad);
         }
     }
+    // the gather copies whole rows: 16-bit rows (even C) are moved as C / 2 four-byte words
+    DycokeArgs g = a;
+    if (dtype != STTM_F32) g.C = C / 2;
     int split = (4096 + T - 1) / T;
     if (split < 1) split = 1;
     if (split > 64) split = 64;
-    const bool vec4 = (C % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0);
-    if (vec4 && C <= 1024) hipLaunchKernelGGL(k_dycoke_gather<4>, dim3(T * split), dim3(256), 0, stream, a, split);
-    else if (vec4 && C <= 2048) hipLaunchKernelGGL(k_dycoke_gather<8>, dim3(T * split), dim3(256), 0, stream, a, split);
-    else if (vec4 && C <= 4096) hipLaunchKernelGGL(k_dycoke_gather<16>, dim3(T * split), dim3(256), 0, stream, a, split);
-    else hipLaunchKernelGGL(k_dycoke_gather<0>, dim3(T * split), dim3(256), 0, stream, a, split);
+    const bool vec4 = (g.C % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0);
+    if (vec4 && g.C <= 1024) hipLaunchKernelGGL(k_dycoke_gather<4>, dim3(T * split), dim3(256), 0, stream, g, split);
+    else if (vec4 && g.C <= 2048) hipLaunchKernelGGL(k_dycoke_gather<8>, dim3(T * split), dim3(256), 0, stream, g, split);
+    else if (vec4 && g.C <= 4096) hipLaunchKernelGGL(k_dycoke_gather<16>, dim3(T * split), dim3(256), 0, stream, g, split);
+    else hipLaunchKernelGGL(k_dycoke_gather<0>, dim3(T * split), dim3(256), 0, stream, g, split);
     return hipGetLastError();
 }
 

@@ -96,8 +96,8 @@ struct TemporalArgs {
                               // leaf offset in the later frame's; the first edge_cnt entries of a list are valid
     int ecap;
     unsigned ecap_magic;      // ceil(2^32 / ecap): j / ecap for j < (T-1) * ecap
-    int pairs_seg;            // k_pairs workgroup map: frames per XCD-local segment (0 = plain t-major order)
-    int pairs_nt;             // k_pairs block size
+    int pairs_seg;            // k_pairs: consecutive frame pairs of one root cell per workgroup
+    int pairs_nt;             // k_pairs block size (power of two, 64 .. 1024)
     float* edge_sim;          // [R][T-1][ecap] similarity of each kept edge (slow_ver only, else null)
     int32_t* edge_cnt;        // [R][T-1]
     int32_t* cand_cnt;        // [R][T-1]
@@ -147,6 +147,7 @@ bool labels_can_fold(const TemporalArgs& a, int n_videos, int* cap);
 hipError_t launch_labels_fused(const TemporalArgs& a, const BatchPtrs& bp, int n_videos, hipStream_t stream);
 hipError_t launch_group_mean(const TemporalArgs& a, const BatchPtrs& bp, int n_videos, hipStream_t stream);
 size_t colscratch_ints(int T, int H, int W, int R);
+void pairs_shape(int T, int R, int n_videos, int want_seg, int want_nt, int* seg, int* nt);
 
 hipError_t launch_pool2d(const void* x, void* out, int T, int H, int W, int C, int OH, int OW, int stride, int mode, int dtype,
                          hipStream_t stream);
@@ -167,7 +168,7 @@ struct OctArgs {
 
 size_t octree_scan_bytes(int64_t n);
 hipError_t launch_octree(OctArgs& a, int dtype, int vec, void* scan_tmp, size_t scan_bytes, hipStream_t stream);
-hipError_t launch_dycoke(const float* x, int T, int P, int C, int k, float* sim, int32_t* keep, float* out, int64_t* out_idx,
+hipError_t launch_dycoke(const void* x, int T, int P, int C, int dtype, int k, float* sim, int32_t* keep, void* out, int64_t* out_idx,
                          hipStream_t stream);
 hipError_t launch_label_edges(const int32_t* pairs, int L, int N, int32_t* rep_out, int32_t* rep2, int32_t* emin,
                               int32_t* iters_out, hipStream_t stream);

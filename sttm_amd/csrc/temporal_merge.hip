@@ -225,7 +225,7 @@ __device__ __forceinline__ bool grid_barrier(int32_t* counter, int target, int32
         int ok = 1;
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(1);
-            if (wall_clock64() - t0 > 20000000ll) { atomicAdd(overflow, 1); ok = 0; break; }    // 0.2 s
+            if (wall_clock64() - t0 > 200000000ll) { atomicAdd(overflow, 1); ok = 0; break; }    // 2 s
         }
         *ok_lds = ok;
     }
@@ -524,114 +524,136 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(const TemporalArgs a
     column_labels_any<MODE>(a, g, blockIdx.x, smem_raw, cap);
 }
 
+// Device facts the residency decisions need (queried once per process; the C ABI serves one device per process the way
+// torch.distributed runs it -- one process per GPU).
+static int device_cus() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 0;
+    }();
+    return n;
+}
+static int device_cus_or(int dflt) { const int n = device_cus(); return n > 0 ? n : dflt; }
+
 // ---------------------------------------------------------------------------------------------------
-// K2: pairs.  One workgroup per (t, root cell): box tests between the node lists of frames t and t+1,
-// then one wave per candidate for the C-long dot product (two candidates in flight per wave).
-// Kept edges go to this workgroup's own list -- no global counters.  With a.fold_labels the workgroup then
-// announces itself on its column's arrival counter, and the last one to arrive runs the column's label stage
-// right here: the stand-alone label kernel (R workgroups, one launch ramp and one tail) disappears.
+// K2: pairs.  One workgroup per (root cell, run of `pairs_seg` consecutive frame pairs): box tests between the node lists of
+// every frame t and t+1 of the run, then one wave per candidate for the C-long dot product (two candidates in flight per
+// wave; the candidates of all pairs of the run form one work list, so the waves stay balanced).  A run reads the node rows
+// of its inner frames for both of their pairs from the same CU (L1 / L2 hits).  Kept edges go to the pair's own list -- no
+// global counters.  With a.fold_labels the workgroup then announces itself on its column's arrival counter, and the last one
+// to arrive runs the column's label stage right here, with all of its (up to 1024) threads: the stand-alone label kernel
+// (R workgroups, one launch ramp and one tail) disappears.
 // ---------------------------------------------------------------------------------------------------
-struct PairShared { int ncand, nkept, last, pad; };
+struct PairShared { int last, pad0, pad1, pad2; };
 
 template <typename T, int VEC>
-__global__ void __launch_bounds__(256, 6) k_pairs(const TemporalArgs a0, const BatchPtrs bp) {
+__global__ void __launch_bounds__(1024) k_pairs(const TemporalArgs a0, const BatchPtrs bp) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const LevelDims& g = a0.dims;          // see k_col_labels
     TemporalArgs a = a0;
     rebase(a, bp, blockIdx.y);
-    PairShared* ps = reinterpret_cast<PairShared*>(smem_raw);
-    int* cand = reinterpret_cast<int*>(smem_raw + sizeof(PairShared));     // [cap] packed (ia << 16 | ib)
 #define STTM_K2_TICK(n) STTM_DEV_TICK(a.dev, k2_ticks, blockIdx.x == a.dev.k2_wg, n)
     STTM_K2_TICK(0);
-    const int R = a.R;
-    int t, r;
-    if (a.pairs_seg > 0) {
-        // XCD-aware map.  Workgroup ids go round-robin over the 8 XCDs, each with its own L2, and the node rows of
-        // (t+1, r) are read by the workgroups of pair t and of pair t+1: keep a run of consecutive frames of one root
-        // cell on ONE XCD so that the second read hits that L2 instead of going to the fabric again.
-        const int L = a.pairs_seg, nf = a.T - 1;
-        const int segs = (nf + L - 1) / L;
-        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
-        const int chunk = (i / L) * 8 + xcd, pos = i % L;
-        if (chunk >= R * segs) return;
-        r = chunk / segs;
-        t = (chunk - r * segs) * L + pos;
-        if (t >= nf) return;
-    } else {
-        t = blockIdx.x / R; r = blockIdx.x % R;
-    }
-    const int HW = a.H * a.W;
-    const int* LA = a.rc_list + (int64_t)(t * R + r) * a.rc_stride;
-    const int* LB = a.rc_list + (int64_t)((t + 1) * R + r) * a.rc_stride;
-    const int cap = a.ecap;
+    const int L = a.pairs_seg, nf = a.T - 1, nseg = (nf + L - 1) / L;
+    const int r = blockIdx.x / nseg, sg = blockIdx.x - r * nseg;
+    const int t0 = sg * L, np = nf - t0 < L ? nf - t0 : L;           // this workgroup: pairs t0 .. t0 + np - 1
+    const int R = a.R, cap = a.ecap, HW = a.H * a.W;
+    PairShared* ps = reinterpret_cast<PairShared*>(smem_raw);
+    int* ncand = reinterpret_cast<int*>(smem_raw + sizeof(PairShared));   // [L]
+    int* nkept = ncand + L;                                               // [L]
+    int* lists = nkept + L;                                               // [L + 1][rc_stride] node lists of frames t0 .. t0 + np
+    int* cand = lists + (L + 1) * a.rc_stride;                            // [L][cap] packed (ia << 16 | ib)
     const Column col = make_column(a, g, r);
-    const int64_t cidx = (int64_t)r * (a.T - 1) + t;          // column-major: a column's lists are contiguous
-    int32_t* my_edges = a.edges + cidx * cap;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
-    // ONE round trip for the counts and the node boxes of both cells: every list entry is fetched speculatively (entries past
-    // the count are stale but inside the row) and parked in LDS for the box tests
-    int* listA = cand + cap;                              // [rc_stride]
-    int* listB = listA + a.rc_stride;                     // [rc_stride]
-    for (int i = tid; i < a.rc_stride; i += blockDim.x) { listA[i] = LA[i]; listB[i] = LB[i]; }
-    if (tid == 0) { ps->ncand = 0; ps->nkept = 0; ps->last = 0; }
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = nt >> 6;
+    // ONE round trip for the counts and the node boxes of every frame of the run: each list entry is fetched speculatively
+    // (entries past the count are stale but inside the row) and parked in LDS for the box tests
+    for (int i = tid; i < (np + 1) * a.rc_stride; i += nt) {
+        const int f = i / a.rc_stride, e = i - f * a.rc_stride;
+        lists[i] = a.rc_list[(int64_t)((t0 + f) * R + r) * a.rc_stride + e];
+    }
+    if (tid < L) { ncand[tid] = 0; nkept[tid] = 0; }
+    if (tid == 0) ps->last = 0;
     __syncthreads();
-    const int nA = listA[0] & 0xffff, nB = listB[0] & 0xffff;
-    // box tests on a (ia, ib) grid whose width is the power of two >= nB: no integer division per test
-    int lg = 0;
-    while ((1 << lg) < nB) ++lg;
-    const int ib = tid & ((1 << lg) - 1), ia0 = tid >> lg, ia_step = blockDim.x >> lg;
-    if (ib < nB && ia_step > 0) {
-        const unsigned bb = (unsigned)listB[1 + ib];
-        const int by1 = bb >> 24, bx1 = (bb >> 16) & 255, by2 = (bb >> 8) & 255, bx2 = bb & 255;
-        for (int ia = ia0; ia < nA; ia += ia_step) {
-            const unsigned ba = (unsigned)listA[1 + ia];
-            const int ay1 = ba >> 24, ax1 = (ba >> 16) & 255, ay2 = (ba >> 8) & 255, ax2 = ba & 255;
-            const bool a_has_b = ay1 <= by1 && ax1 <= bx1 && ay2 >= by2 && ax2 >= bx2;
-            const bool b_has_a = ay1 >= by1 && ax1 >= bx1 && ay2 <= by2 && ax2 <= bx2;
-            if (a_has_b || b_has_a) {
-                const int pos = atomicAdd(&ps->ncand, 1);
-                if (pos < cap) cand[pos] = (ia << 16) | ib;
-            }
-        }
-    } else if (ia_step == 0) {                            // more nodes in the cell than threads (block-size override): plain loop
-        for (int p = tid; p < nA * nB; p += blockDim.x) {
-            const int ia = p / nB, jb = p - ia * nB;
-            const unsigned ba = (unsigned)listA[1 + ia], bb = (unsigned)listB[1 + jb];
-            const int ay1 = ba >> 24, ax1 = (ba >> 16) & 255, ay2 = (ba >> 8) & 255, ax2 = ba & 255;
-            const int by1 = bb >> 24, bx1 = (bb >> 16) & 255, by2 = (bb >> 8) & 255, bx2 = bb & 255;
-            if ((ay1 <= by1 && ax1 <= bx1 && ay2 >= by2 && ax2 >= bx2) || (ay1 >= by1 && ax1 >= bx1 && ay2 <= by2 && ax2 <= bx2)) {
-                const int pos = atomicAdd(&ps->ncand, 1);
-                if (pos < cap) cand[pos] = (ia << 16) | jb;
+    {
+        // box tests: the threads are split evenly over the pairs (tpp each, a power of two); inside a pair they walk an
+        // (ia, ib) grid whose width is the power of two >= nB, so no integer division per test
+        int lp2 = 0;
+        while ((1 << lp2) < L) ++lp2;
+        const int tpp = nt >> lp2, p = tid >> (31 - __clz(tpp)), lt = tid & (tpp - 1);
+        if (p < np) {
+            const int* listA = lists + p * a.rc_stride;
+            const int* listB = listA + a.rc_stride;
+            const int nA = listA[0] & 0xffff, nB = listB[0] & 0xffff;
+            int lg = 0;
+            while ((1 << lg) < nB) ++lg;
+            auto test = [&](int ia, int ib) {
+                const unsigned ba = (unsigned)listA[1 + ia], bb = (unsigned)listB[1 + ib];
+                const int ay1 = ba >> 24, ax1 = (ba >> 16) & 255, ay2 = (ba >> 8) & 255, ax2 = ba & 255;
+                const int by1 = bb >> 24, bx1 = (bb >> 16) & 255, by2 = (bb >> 8) & 255, bx2 = bb & 255;
+                const bool a_has_b = ay1 <= by1 && ax1 <= bx1 && ay2 >= by2 && ax2 >= bx2;
+                const bool b_has_a = ay1 >= by1 && ax1 >= bx1 && ay2 <= by2 && ax2 <= bx2;
+                if (a_has_b || b_has_a) {
+                    const int pos = atomicAdd(&ncand[p], 1);
+                    if (pos < cap) cand[p * cap + pos] = (ia << 16) | ib;
+                }
+            };
+            if ((1 << lg) <= tpp) {
+                const int ib = lt & ((1 << lg) - 1);
+                if (ib < nB)
+                    for (int ia = lt >> lg; ia < nA; ia += tpp >> lg) test(ia, ib);
+            } else {                                          // more nodes in the cell than threads per pair: plain loop
+                for (int q = lt; q < nA * nB; q += tpp) { const int ia = q / nB; test(ia, q - ia * nB); }
             }
         }
     }
     __syncthreads();
     STTM_K2_TICK(1);
-    const int ncand = ps->ncand;
-    const int nc = ncand < cap ? ncand : cap;
-    auto row_of = [&](const int* L, int i, int frame) {
-        const unsigned b = (unsigned)L[1 + i];
+    // flat work list over the run's candidates: entry c belongs to the pair p with base(p) <= c < base(p + 1)
+    int total = 0;
+    for (int p = 0; p < np; ++p) total += ncand[p] < cap ? ncand[p] : cap;
+    struct Cand { int p, k; };
+    auto locate = [&](int c) {
+        Cand o; o.p = 0;
+        int base = 0;
+        while (o.p < np - 1) {
+            const int n = ncand[o.p] < cap ? ncand[o.p] : cap;
+            if (c < base + n) break;
+            base += n; ++o.p;
+        }
+        o.k = cand[o.p * cap + (c - base)];
+        return o;
+    };
+    auto row_of = [&](const int* Lst, int i, int frame) {
+        const unsigned b = (unsigned)Lst[1 + i];
         return frame * HW + (int)(b >> 24) * a.W + (int)((b >> 16) & 255);
     };
     // offset of a list entry's origin leaf inside the root cell, straight from its box
-    auto leaf_of = [&](const int* L, int i) {
-        const unsigned b = (unsigned)L[1 + i];
+    auto leaf_of = [&](const int* Lst, int i) {
+        const unsigned b = (unsigned)Lst[1 + i];
         return (unsigned)(((int)(b >> 24) - col.Y1) * col.aw + ((int)((b >> 16) & 255) - col.X1));
     };
-    auto src_of = [&](const int* L, int i) -> const void* {      // 1x1 nodes were not copied out of x
-        const unsigned b = (unsigned)L[1 + i];
+    auto src_of = [&](const int* Lst, int i) -> const void* {      // 1x1 nodes were not copied out of x
+        const unsigned b = (unsigned)Lst[1 + i];
         const bool leaf = ((b >> 8) & 255) - (b >> 24) == 1 && (b & 255) - ((b >> 16) & 255) == 1;
         return (leaf && a.xrows) ? a.xrows : a.S;
     };
     // kept edges are published with agent-scope (write-through) stores: their reader may be another workgroup of
     // this launch (the column's last arriver), possibly on another XCD
+    auto keep = [&](const Cand& cd, float sim) {
+        const int e = atomicAdd(&nkept[cd.p], 1);
+        const int64_t cidx = (int64_t)r * nf + (t0 + cd.p);          // column-major: a column's lists are contiguous
+        const int* lA = lists + cd.p * a.rc_stride;
+        if (a.edge_sim) a.edge_sim[cidx * cap + e] = sim;
+        st_agent(a.edges + cidx * cap + e, (int)((leaf_of(lA, cd.k >> 16) << 16) | leaf_of(lA + a.rc_stride, cd.k & 0xffff)));
+    };
     if (a.n_head > 0) {
         // per-head cosine, averaged over heads (quadtree_temporal_merger.py:65-68): G adjacent lanes own one head
         const int G = a.head_lanes;
-        for (int c = wave; c < nc; c += nwave) {
-            const int k0 = cand[c];
-            const int rowA = row_of(listA, k0 >> 16, t), rowB = row_of(listB, k0 & 0xffff, t + 1);
-            const void* sA = src_of(listA, k0 >> 16); const void* sB = src_of(listB, k0 & 0xffff);
+        for (int c = wave; c < total; c += nwave) {
+            const Cand cd = locate(c);
+            const int* lA = lists + cd.p * a.rc_stride; const int* lB = lA + a.rc_stride;
+            const int rowA = row_of(lA, cd.k >> 16, t0 + cd.p), rowB = row_of(lB, cd.k & 0xffff, t0 + cd.p + 1);
+            const void* sA = src_of(lA, cd.k >> 16); const void* sB = src_of(lB, cd.k & 0xffff);
             float acc = 0.f;
             for (int base = 0; base < a.C; base += 64 * VEC) {
                 const int c0 = base + lane * VEC;
@@ -647,20 +669,20 @@ __global__ void __launch_bounds__(256, 6) k_pairs(const TemporalArgs a0, const B
                 if ((lane & (G - 1)) == 0 && c0 < a.C) acc += d / ((sqrtf(na) + 1e-8f) * (sqrtf(nb) + 1e-8f));
             }
             acc = wave_sum(acc);
-            if (lane == 0 && acc / (float)a.n_head >= a.temporal_thresh) {
-                const int e = atomicAdd(&ps->nkept, 1);
-                st_agent(my_edges + e, (int)((leaf_of(listA, k0 >> 16) << 16) | leaf_of(listB, k0 & 0xffff)));
-            }
+            const float sim = acc / (float)a.n_head;
+            if (lane == 0 && sim >= a.temporal_thresh) keep(cd, sim);
         }
     } else
-    for (int c = wave; c < nc; c += 2 * nwave) {
+    for (int c = wave; c < total; c += 2 * nwave) {
         const int c2 = c + nwave;
-        const bool two = c2 < nc;
-        const int k0 = cand[c], k1 = two ? cand[c2] : k0;
-        const int rowA0 = row_of(listA, k0 >> 16, t), rowB0 = row_of(listB, k0 & 0xffff, t + 1);
-        const int rowA1 = row_of(listA, k1 >> 16, t), rowB1 = row_of(listB, k1 & 0xffff, t + 1);
-        const void* sA0 = src_of(listA, k0 >> 16); const void* sB0 = src_of(listB, k0 & 0xffff);
-        const void* sA1 = src_of(listA, k1 >> 16); const void* sB1 = src_of(listB, k1 & 0xffff);
+        const bool two = c2 < total;
+        const Cand q0 = locate(c), q1 = two ? locate(c2) : q0;
+        const int* lA0 = lists + q0.p * a.rc_stride; const int* lB0 = lA0 + a.rc_stride;
+        const int* lA1 = lists + q1.p * a.rc_stride; const int* lB1 = lA1 + a.rc_stride;
+        const int rowA0 = row_of(lA0, q0.k >> 16, t0 + q0.p), rowB0 = row_of(lB0, q0.k & 0xffff, t0 + q0.p + 1);
+        const int rowA1 = row_of(lA1, q1.k >> 16, t0 + q1.p), rowB1 = row_of(lB1, q1.k & 0xffff, t0 + q1.p + 1);
+        const void* sA0 = src_of(lA0, q0.k >> 16); const void* sB0 = src_of(lB0, q0.k & 0xffff);
+        const void* sA1 = src_of(lA1, q1.k >> 16); const void* sB1 = src_of(lB1, q1.k & 0xffff);
         // the two lanes that finish the cosines fetch their inverse norms now, under the row loads
         double pre_ia = 0.0, pre_ib = 0.0;
         if (lane < 2 && !a.inline_norms) {
@@ -690,26 +712,26 @@ __global__ void __launch_bounds__(256, 6) k_pairs(const TemporalArgs a0, const B
             const double ia = a.inline_norms ? 1.0 / (sqrt((double)(lane ? na1 : na0)) + 1e-8) : pre_ia;
             const double ib = a.inline_norms ? 1.0 / (sqrt((double)(lane ? nb1 : nb0)) + 1e-8) : pre_ib;
             const float sim = (float)((double)dot * ia * ib);
-            if (sim >= a.temporal_thresh) {
-                const int e = atomicAdd(&ps->nkept, 1);
-                if (a.edge_sim) a.edge_sim[cidx * cap + e] = sim;
-                const int kk = lane ? k1 : k0;
-                st_agent(my_edges + e, (int)((leaf_of(listA, kk >> 16) << 16) | leaf_of(listB, kk & 0xffff)));
-            }
+            if (sim >= a.temporal_thresh) keep(lane ? q1 : q0, sim);
         }
     }
-    // every wave's edge stores have left before the count says they are there
+    // every wave's edge stores have left before the counts say they are there
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     STTM_K2_TICK(2);
-    if (tid == 0) {
-        st_agent(a.edge_cnt + cidx, ps->nkept);
-        st_agent(a.cand_cnt + cidx, ncand);
-        if (ncand > cap) atomicAdd(a.counts + STTM_CNT_OVERFLOW, 1);        // cannot happen: nested-or-disjoint boxes give < 2A pairs
+    if (wave == 0) {
+        if (lane < np) {
+            const int64_t cidx = (int64_t)r * nf + (t0 + lane);
+            st_agent(a.edge_cnt + cidx, nkept[lane]);
+            st_agent(a.cand_cnt + cidx, ncand[lane]);
+            if (ncand[lane] > cap) atomicAdd(a.counts + STTM_CNT_OVERFLOW, 1);     // cannot happen: nested-or-disjoint boxes give < 2A pairs
+        }
         if (a.fold_labels) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const int old = __hip_atomic_fetch_add(a.col_arrive + r, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ps->last = old == a.T - 2 ? 1 : 0;
+            if (lane == 0) {
+                const int old = __hip_atomic_fetch_add(a.col_arrive + r, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ps->last = old == nseg - 1 ? 1 : 0;
+            }
         }
     }
     STTM_K2_TICK(3);
@@ -723,16 +745,14 @@ __global__ void __launch_bounds__(256, 6) k_pairs(const TemporalArgs a0, const B
 }
 
 static size_t pairs_smem(const TemporalArgs& a) {
-    return sizeof(PairShared) + sizeof(int) * ((size_t)a.ecap + 2 * (size_t)a.rc_stride);      // candidates + the two node lists
+    const size_t L = a.pairs_seg;
+    return sizeof(PairShared) + sizeof(int) * (2 * L + (L + 1) * (size_t)a.rc_stride + L * (size_t)a.ecap);
 }
 
 hipError_t launch_pairs(const TemporalArgs& a, const BatchPtrs& bp, int n_videos, hipStream_t stream) {
     if (a.T < 2) return hipSuccess;
-    int grid = (a.T - 1) * a.R;
-    if (a.pairs_seg > 0) {
-        const int segs = (a.T - 1 + a.pairs_seg - 1) / a.pairs_seg;
-        grid = 8 * ((a.R * segs + 7) / 8) * a.pairs_seg;
-    }
+    const int nseg = (a.T - 1 + a.pairs_seg - 1) / a.pairs_seg;
+    const int grid = a.R * nseg;
     size_t smem = pairs_smem(a);
     if (a.fold_labels) {
         const size_t lb = col_lds_bytes(a.fold_cap, a.max_slots, a.T);
@@ -751,24 +771,35 @@ hipError_t launch_pairs(const TemporalArgs& a, const BatchPtrs& bp, int n_videos
     return hipGetLastError();
 }
 
-// Device facts the residency decisions need (queried once per process; the C ABI serves one device per process the way
-// torch.distributed runs it -- one process per GPU).
-static int device_cus() {
-    static const int n = [] {
-        int dev = 0, v = 0;
-        return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 0;
-    }();
-    return n;
+// frame pairs per pair workgroup and its block size: about one workgroup per CU (the runs of all columns then run side by
+// side in one round), 128 threads per pair of the run, 256 .. 1024 threads
+void pairs_shape(int T, int R, int n_videos, int want_seg, int want_nt, int* seg, int* nt) {
+    const int nf = T > 1 ? T - 1 : 1;
+    int cus = device_cus_or(256);
+    long cells = (long)nf * R * n_videos;
+    int L = want_seg > 0 ? want_seg : (int)((cells + cus - 1) / cus);
+    if (L < 1) L = 1;
+    if (L > 16) L = 16;
+    if (L > nf) L = nf;
+    int n = want_nt > 0 ? want_nt : 128 * L;
+    const int lo = want_nt > 0 ? 64 : 256;
+    if (n < lo) n = lo;
+    if (n > 1024) n = 1024;
+    // the threads of a run are split evenly over a power-of-two number of pairs: the block size is a power of two
+    int p2 = 64;
+    while (p2 * 2 <= n) p2 *= 2;
+    *seg = L; *nt = p2;
 }
 
-// Fold the label stage into the pair kernel when (a) there is a pair kernel and no slow_ver filter between the two,
-// (b) a useful number of active nodes fits beside 6+ resident pair workgroups per CU, and (c) the R workgroups that wait for
-// each other at the in-kernel grid barrier are a small part of what the device holds at once, so they are all resident
-// while every other workgroup of the launch runs to completion.
+
+// Fold the label stage into the pair kernel when (a) there is a pair kernel and no slow_ver filter between the two, (b) the
+// column's active nodes get a useful amount of LDS, and (c) the R * n_videos workgroups that wait for each other at the
+// in-kernel grid barrier occupy at most half of the CUs (a 1024-thread workgroup can take a CU for itself), so every other
+// workgroup of the launch still finds a CU and runs to completion.
 bool labels_can_fold(const TemporalArgs& a, int n_videos, int* cap) {
     if (a.no_fold || a.slow_ver || !(a.temporal_thresh > 0.f) || a.T < 2) return false;
     const int cus = device_cus();
-    if (cus <= 0 || (long long)a.R * n_videos > cus) return false;      // <= one waiting workgroup per CU, each CU holds several
+    if (cus <= 0 || (long long)a.R * n_videos > cus / 2) return false;
     const size_t budget = (size_t)a.fold_kb * 1024;
     const size_t fixed = col_lds_bytes(0, a.max_slots, a.T);
     if (fixed + 16 * 256 > budget) return false;
@@ -910,7 +941,9 @@ bool labels_can_fuse(const TemporalArgs& a, int n_videos) {
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_col_labels<COL_FUSED>, col_threads(a), smem) != hipSuccess || per_cu < 1)
         return false;
-    return (long long)a.R * n_videos <= (long long)per_cu * cus / 2;       // half: other streams may hold part of the device
+    // a quarter of what the API promises: it answers one block per CU too many for kernels with > 80 SGPRs
+    // (MI355X_MICROARCH.md, residency), and other streams may hold part of the device
+    return (long long)a.R * n_videos <= (long long)per_cu * cus / 4;
 }
 
 hipError_t launch_labels_fused(const TemporalArgs& a, const BatchPtrs& bp, int n_videos, hipStream_t stream) {

@@ -2,7 +2,7 @@
 (token_merging_utils/dycoke_merger.py:8-83), the function its "dycoke-stage1" hook calls
 (token_merging_monkey_patch/dycoke_stage1_attn_monkey_patch.py:97).
 
-Device only (HIP kernels in csrc/dycoke.hip), float32 only; every size is known in advance, so nothing here
+Device only (HIP kernels in csrc/dycoke.hip), float32 / bfloat16 / float16; every size is known in advance, so nothing here
 synchronises the stream.  Where two tokens of a frame have exactly the same similarity, `torch.topk` leaves their order
 unspecified; this implementation puts the smaller token id first.
 """
@@ -19,8 +19,9 @@ def dycoke_ttm(image_feature, num_frames, prune_ratio=0.7):
         raise RuntimeError("sttm_amd runs on the GPU only: the input must be a CUDA (ROCm) tensor; there is no CPU fallback")
     if image_feature.dim() != 2:
         raise ValueError("expected a [num_frames * tokens_per_frame, C] tensor")
-    if image_feature.dtype != torch.float32:
-        raise NotImplementedError("dycoke_ttm on the device path is float32 only")
+    codes = {torch.float32: _lib.STTM_F32, torch.bfloat16: _lib.STTM_BF16, torch.float16: _lib.STTM_F16}
+    if image_feature.dtype not in codes:
+        raise NotImplementedError(f"dtype {image_feature.dtype} is not supported (float32, bfloat16, float16)")
     T = int(num_frames)
     P = image_feature.shape[0] // T                                      # :11
     C = image_feature.shape[1]
@@ -43,7 +44,7 @@ def dycoke_ttm(image_feature, num_frames, prune_ratio=0.7):
             _ws_cache[key] = ws
         out = torch.empty((rows, C), dtype=x.dtype, device=dev)
         idx = torch.empty(rows, dtype=torch.int64, device=dev)
-        rc = lib.sttm_dycoke_ttm(x.data_ptr(), T, P, C, 0, k, ws.data_ptr(), ws.numel(), out.data_ptr(), idx.data_ptr(),
+        rc = lib.sttm_dycoke_ttm(x.data_ptr(), T, P, C, codes[x.dtype], k, ws.data_ptr(), ws.numel(), out.data_ptr(), idx.data_ptr(),
                                  stream.cuda_stream)
     _lib.raise_for(rc)
     return out, idx

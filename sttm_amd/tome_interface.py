@@ -4,6 +4,8 @@
 quirks: "video" works, "frame" raises RuntimeError for T > 1, "snippet" and unknown
 versions return None.  The per-video loop (tome_token_merger.py:133-152) runs on the device with no host
 synchronisation at all: the number of tokens after every iteration is known on the host in advance.
+float32, bfloat16 and float16 inputs (the hook hands over the decoder's hidden states, bf16 in production); 16-bit inputs
+follow the reference's per-op rounding to the input dtype (csrc/tome.hip).
 """
 import math
 
@@ -11,13 +13,16 @@ import torch
 
 from . import _lib
 
+_DTYPE_CODE = {torch.float32: _lib.STTM_F32, torch.bfloat16: _lib.STTM_BF16, torch.float16: _lib.STTM_F16}
+
 
 def _tome_video(x_tchw, prune_ratio, n_head):
     if not x_tchw.is_cuda:
         raise RuntimeError("sttm_amd runs on the GPU only: the input must be a CUDA (ROCm) tensor; "
                            "there is no CPU fallback")
-    if x_tchw.dtype != torch.float32:
-        raise NotImplementedError("the device ToMe path is float32 only for now")
+    if x_tchw.dtype not in _DTYPE_CODE:
+        raise NotImplementedError(f"dtype {x_tchw.dtype} is not supported (float32, bfloat16, float16)")
+    dtype = _DTYPE_CODE[x_tchw.dtype]
     lib = _lib.load()
     T, C, H, W = x_tchw.shape
     x = x_tchw.permute(0, 2, 3, 1).reshape(T * H * W, C)           # view for the production layout
@@ -42,11 +47,11 @@ def _tome_video(x_tchw, prune_ratio, n_head):
             if nbytes == 0:
                 raise ValueError(f"bad ToMe configuration n={n} C={C} n_head={n_head}")
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            x_out = torch.empty((n - r, C), dtype=torch.float32, device=dev)
+            x_out = torch.empty((n - r, C), dtype=x.dtype, device=dev)
             size_out = torch.empty(n - r, dtype=torch.float32, device=dev)
             idx_out = torch.empty(n - r, dtype=torch.int64, device=dev)
             rc = lib.sttm_tome_step(x.data_ptr(), size.data_ptr() if size is not None else None, idx.data_ptr(),
-                                    n, C, int(n_head), r, _lib.STTM_F32, ws.data_ptr(), nbytes,
+                                    n, C, int(n_head), r, dtype, ws.data_ptr(), nbytes,
                                     x_out.data_ptr(), size_out.data_ptr(), idx_out.data_ptr(), None, None,
                                     stream.cuda_stream)
             _lib.raise_for(rc)

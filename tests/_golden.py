@@ -13,6 +13,8 @@ def _t(a, dtype):
     t = torch.from_numpy(np.ascontiguousarray(a))
     if dtype == "bfloat16":
         t = t.view(torch.bfloat16)
+    elif dtype == "float16":
+        t = t.view(torch.float16)
     return t
 
 

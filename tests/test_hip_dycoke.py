@@ -105,3 +105,39 @@ def test_dycoke_stage1_pattern_runs_on_device():
         assert out.shape == ref.shape and torch.allclose(out, ref, atol=2e-5)
     finally:
         MPI.restore_qwen2()
+
+
+def _frames_of(idx, P, T):
+    return [set((idx[(idx // P) == f] % P).tolist()) for f in range(T)]
+
+
+@pytest.mark.parametrize("name", ["dyc16_bf16_t8", "dyc16_bf16_t9_c256", "dyc16_f16_t8", "dyc16_f16_t12_c100"])
+def test_dycoke_16bit_golden_vectors(name):
+    """bfloat16 / float16 hidden states (what the reference's hook passes, dycoke_stage1_attn_monkey_patch.py:88-107).  The
+    similarities are rounded to the input dtype, so `topk` has ties: per frame, the kept tokens must agree as sets except for
+    tokens whose similarity EQUALS the cut value (or sits within one 16-bit ulp of it: fp32 summation order)."""
+    import json
+    import numpy as np
+    from sttm_amd.dycoke_merger import dycoke_ttm
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    meta = json.loads(str(z["meta"]))
+    dt = getattr(torch, meta["dtype"])
+    x = torch.from_numpy(z["x"]).view(dt)
+    exp_i = torch.from_numpy(z["idx"])
+    sims = torch.from_numpy(z["sims"])
+    T, P = meta["T"], meta["side"] ** 2
+    out, oi = dycoke_ttm(x.to(DEV), T, meta["prune"])
+    out, oi = out.cpu(), oi.cpu()
+    assert out.dtype == dt and oi.shape == exp_i.shape
+    assert torch.equal(out.view(torch.int16), x[oi].view(torch.int16))                     # rows are exact copies
+    ulp = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10
+    agree = total = 0
+    for f, (got, exp) in enumerate(zip(_frames_of(oi, P, T), _frames_of(exp_i, P, T))):
+        assert len(got) == len(exp)
+        total += len(exp); agree += len(got & exp)
+        if got != exp:
+            cut = max(float(sims[f, p]) for p in exp)                                      # largest kept similarity = the cut value
+            for p in got ^ exp:
+                assert abs(float(sims[f, p]) - cut) <= 2 * ulp * max(1.0, abs(cut)), (f, p, float(sims[f, p]), cut)
+    print(f"{name}: {agree}/{total} kept tokens identical")
+    assert agree >= 0.9 * total

@@ -89,3 +89,15 @@ def test_level_sizes_quirk_q5():
     assert O.level_sizes(10, 30) == [(2, 4), (3, 8), (5, 15), (10, 30)]
     assert O.level_sizes(14, 14) == [(2, 2), (4, 4), (7, 7), (14, 14)]
     assert O.level_sizes(20, 36) == [(2, 3), (3, 5), (5, 9), (10, 18), (20, 36)]
+
+
+@pytest.mark.parametrize("path", case_paths(["tome16_"]), ids=os.path.basename)
+def test_oracle_tome_16bit_vectors(path):
+    """ToMe on bfloat16 / float16 inputs: the oracle issues the same ATen calls as the reference on the input dtype, so on the
+    machine that made the vectors it reproduces them exactly (ids and features)."""
+    from oracle import sttm_oracle as O
+    c = load_case(path)
+    m = c["meta"]
+    feat, idx = O.get_tome_features(c["x"], m["ratio"], "video", m["n_head"])
+    assert feat.dtype == c["feat"].dtype and torch.equal(idx, c["idx"])
+    assert torch.equal(feat.view(torch.int16), c["feat"].view(torch.int16))
