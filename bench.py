@@ -257,13 +257,14 @@ def main():
     n_prof = max(8, min(args.profile_calls, K * V))
     for i in range(n_prof):
         x = pool[i % P]
-        _, _, _, cnt = quadtree_merge_raw(x, thr, tthr, root, False, None, events=ev)
-        ms = ev.elapsed_ms()
+        _, _, _, cnt, ctx = quadtree_merge_raw(x, thr, tthr, root, False, None, events=ev, return_ctx=True)
+        ms = ev.elapsed_ms()                 # waits for the call's last event
         for k in range(4):
             tot[k] += ms[k]
         span += sum(ms)
-        nodes += cnt[_lib.CNT_NODES]
-        leafnodes += cnt[_lib.CNT_LEAFNODES]
+        dcnt = ctx[2][0].tolist()            # the diagnostic counters live in device memory (complete once the call has drained)
+        nodes += dcnt[_lib.CNT_NODES]
+        leafnodes += dcnt[_lib.CNT_LEAFNODES]
         merged += cnt[_lib.CNT_OUT]
         calls += 1
     log("roofline leg done: " + ", ".join(f"{k}={t / calls:.4f} ms" for k, t in zip(KERNELS, tot)))

@@ -142,13 +142,15 @@ int sttm_quadtree_merge_batch(int n_videos, const void* const* x, int64_t stride
  * Tuning and test switches (process-wide; none of them changes results).  Defaults come from the environment variable
  * STTM_<KEY> read once at first use; sttm_configure overrides a key at run time (call it while no merge is being issued from
  * another thread).  Returns STTM_ERR_ARG for an unknown key.  Keys:
- *   "pairs_seg"   consecutive frame pairs of one root cell per pair workgroup (0 = automatic: about one workgroup per CU)
- *   "pairs_nt"    pair-kernel block size (0 = automatic: 128 threads per frame pair of the run, 256 .. 1024)
+ *   "pairs_seg"   consecutive frame pairs of one root cell per pair workgroup (0 = automatic: 1; with fold_labels about one
+ *                 workgroup per CU)
+ *   "pairs_nt"    pair-kernel block size (0 = automatic: 256 for one pair, 128 threads per pair of a run, up to 1024)
  *   "gm_split"    group-mean workgroups per frame (0 = automatic)
  *   "label_nt"    threads per column of the stand-alone label kernels (256 / 512 / 1024)
  *   "vec16" / "vec32"   force the pack width of 16-bit / 32-bit inputs in the spatial kernel (0 = automatic)
  *   "fold_kb"     LDS budget (KB) per pair workgroup when the label stage runs inside the pair kernel (default 64)
- *   "no_fold"     1: never run the label stage inside the pair kernel (stand-alone label kernel instead)
+ *   "fold_labels" 1: run a column's label stage inside the pair kernel, in the column's last workgroup to finish (default 0:
+ *                 stand-alone label kernel; the folded form is no faster on MI355X and is kept for experiments)
  *   "no_fuse"     1: stand-alone label stage as two launches (no in-kernel grid barrier)
  *   "force_gmem_labels"  1: label stage on global scratch instead of LDS (the path of columns too large for LDS)
  */

@@ -24,7 +24,7 @@ int fail(int code, const char* fmt, ...) {
 // Tuning / test switches: defaults from STTM_<KEY> environment variables, read ONCE; sttm_configure overrides them.
 // None of them changes results.
 struct Config {
-    int pairs_seg, pairs_nt, gm_split, label_nt, vec16, vec32, fold_kb, no_fold, no_fuse, force_gmem_labels;
+    int pairs_seg, pairs_nt, gm_split, label_nt, vec16, vec32, fold_kb, fold_labels, no_fuse, force_gmem_labels;
 };
 int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
@@ -40,7 +40,7 @@ Config& config() {
         d.vec16 = env_int("STTM_VEC16", 0);
         d.vec32 = env_int("STTM_VEC32", 0);
         d.fold_kb = env_int("STTM_FOLD_KB", 64);
-        d.no_fold = env_int("STTM_NO_FOLD", 0);
+        d.fold_labels = env_int("STTM_FOLD_LABELS", 0);
         d.no_fuse = env_int("STTM_NO_FUSE", env_int("STTM_NO_FUSE_LABELS", 0));
         d.force_gmem_labels = env_int("STTM_FORCE_GMEM_LABELS", 0);
         return d;
@@ -372,7 +372,7 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
     ta.T = T; ta.H = H; ta.W = W; ta.C = C; ta.R = p.R;
     ta.dims = p.dims;
     ta.dtype = dtype; ta.vec = row_vec(C, dtype, vec, dense, all_bits % 32 == 0, head_dim);
-    sttm::pairs_shape(T, p.R, nv, cfg.pairs_seg, cfg.pairs_nt, &ta.pairs_seg, &ta.pairs_nt);
+    sttm::pairs_shape(T, p.R, cfg.fold_labels && !slow_ver, cfg.pairs_seg, cfg.pairs_nt, &ta.pairs_seg, &ta.pairs_nt);
     ta.label_nt = (cfg.label_nt == 256 || cfg.label_nt == 512) ? cfg.label_nt : 1024;
     ta.temporal_thresh = temporal_thresh;
     ta.weighted_avg = weighted_avg ? 1 : 0;
@@ -383,7 +383,7 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
     ta.max_slots = p.max_slots;
     ta.force_gmem = cfg.force_gmem_labels ? 1 : 0;
     ta.no_fuse = cfg.no_fuse ? 1 : 0;
-    ta.no_fold = cfg.no_fold ? 1 : 0;
+    ta.want_fold = cfg.fold_labels ? 1 : 0;
     ta.fold_kb = cfg.fold_kb > 0 ? cfg.fold_kb : 64;
     ta.S = b.S; ta.xrows = dense ? x[0] : nullptr; ta.meta = b.meta; ta.inrm = b.inrm; ta.rc_list = b.rc_list; ta.rc_stride = p.rc_stride;
     ta.edges = b.edges; ta.edge_sim = slow_ver ? b.edge_sim : nullptr; ta.ecap = p.ecap; ta.edge_cnt = b.edge_cnt; ta.cand_cnt = b.cand_cnt;
@@ -454,7 +454,7 @@ int sttm_configure(const char* key, int value) {
     Config& c = config();
     struct { const char* name; int* slot; } keys[] = {
         {"pairs_seg", &c.pairs_seg}, {"pairs_nt", &c.pairs_nt}, {"gm_split", &c.gm_split}, {"label_nt", &c.label_nt},
-        {"vec16", &c.vec16}, {"vec32", &c.vec32}, {"fold_kb", &c.fold_kb}, {"no_fold", &c.no_fold}, {"no_fuse", &c.no_fuse},
+        {"vec16", &c.vec16}, {"vec32", &c.vec32}, {"fold_kb", &c.fold_kb}, {"fold_labels", &c.fold_labels}, {"no_fuse", &c.no_fuse},
         {"force_gmem_labels", &c.force_gmem_labels},
     };
     for (auto& k : keys)
@@ -602,6 +602,7 @@ int sttm_wait_counts(const int32_t* counts_host, int seq, int timeout_us) {
 // development build only (not in the public header): measurement hooks of tools/*_ticks.py and tools/k1_ablate.py.
 // ticks: device buffer of >= 48 long longs -- [0, 16) spatial workgroup k1_wg, [16, 32) pair workgroup k2_wg, [32, 48) label
 // stage of column lbl_col -- or NULL to switch the stamps off.
+int sttm_dev_k1_span(long long* span) { g_dev.k1_span = span; return STTM_OK; }   // [2 * T * R] device buffer or NULL
 int sttm_dev_hooks(int k1_mode, long long* ticks, int k1_wg, int k2_wg, int lbl_col) {
     g_dev.k1_mode = k1_mode;
     g_dev.k1_ticks = ticks; g_dev.k1_wg = k1_wg;

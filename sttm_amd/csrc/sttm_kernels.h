@@ -16,6 +16,7 @@ struct DevHooks {
     int k2_wg;
     long long* lbl_ticks;     // stamps of the label stage of column lbl_col
     int lbl_col;
+    long long* k1_span;       // [2 * workgroups] start / end stamp of EVERY spatial workgroup (null = off)
 };
 #define STTM_DEV_TICK(hooks, field, sel, n) \
     do { if ((hooks).field && (sel) && threadIdx.x == 0) (hooks).field[n] = wall_clock64(); } while (0)
@@ -105,7 +106,7 @@ struct TemporalArgs {
     int32_t* col_arrive;      // [R] arrivals of a column's pair workgroups (zeroed by the spatial kernel)
     int32_t* frame_cnt;       // [T] survivors per frame (zeroed by the spatial kernel)
     int32_t* bar;             // [4] grid-barrier counter + arrival word (zeroed by the spatial kernel)
-    int no_fuse, no_fold;     // options: two-launch label path / no label stage inside the pair kernel
+    int no_fuse, want_fold;   // options: two-launch label path / label stage inside the pair kernel (opt-in)
     int fold_kb;              // LDS budget (KB) of a pair workgroup when the label stage is folded in
     int fold_labels;          // the last pair workgroup of a column to arrive runs that column's label stage
     int fold_cap;             // ... with room for this many active nodes / kept edges in LDS (global scratch beyond)
@@ -147,7 +148,7 @@ bool labels_can_fold(const TemporalArgs& a, int n_videos, int* cap);
 hipError_t launch_labels_fused(const TemporalArgs& a, const BatchPtrs& bp, int n_videos, hipStream_t stream);
 hipError_t launch_group_mean(const TemporalArgs& a, const BatchPtrs& bp, int n_videos, hipStream_t stream);
 size_t colscratch_ints(int T, int H, int W, int R);
-void pairs_shape(int T, int R, int n_videos, int want_seg, int want_nt, int* seg, int* nt);
+void pairs_shape(int T, int R, int fold, int want_seg, int want_nt, int* seg, int* nt);
 
 hipError_t launch_pool2d(const void* x, void* out, int T, int H, int W, int C, int OH, int OW, int stride, int mode, int dtype,
                          hipStream_t stream);

@@ -211,9 +211,9 @@ __device__ __forceinline__ void column_iteration(int* rep, int* rep2, const int*
 }
 
 // Grid-wide barrier among the column workgroups (all resident: see labels_can_fuse / labels_can_fold).  The spin is
-// bounded: on a timeout the overflow counter is raised (the Python wrapper then fails loudly) and false is returned --
-// the caller skips the rest of its column instead of continuing with partial data.
-__device__ __forceinline__ bool grid_barrier(int32_t* counter, int target, int32_t* overflow, int* ok_lds) {
+// bounded: on a timeout false is returned -- the caller skips the rest of its column instead of continuing with partial data
+// and reports the overflow through the arrival word (the Python wrapper then fails loudly).
+__device__ __forceinline__ bool grid_barrier(int32_t* counter, int target, int* ok_lds) {
     // Everything that crosses this barrier is written with agent-scope (write-through, sc1) stores or atomics and read
     // with agent-scope loads, so no release/acquire cache maintenance is needed: every wave drains its stores, one lane
     // arrives and polls the counter.
@@ -225,7 +225,7 @@ __device__ __forceinline__ bool grid_barrier(int32_t* counter, int target, int32
         int ok = 1;
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(1);
-            if (wall_clock64() - t0 > 200000000ll) { atomicAdd(overflow, 1); ok = 0; break; }    // 2 s
+            if (wall_clock64() - t0 > 200000000ll) { ok = 0; break; }    // 2 s
         }
         *ok_lds = ok;
     }
@@ -233,13 +233,15 @@ __device__ __forceinline__ bool grid_barrier(int32_t* counter, int target, int32
     return *ok_lds != 0;
 }
 
-__device__ __forceinline__ void publish_counts(const TemporalArgs& a, int n_out) {
+// N' (and the overflow flag) go straight into pinned host memory: the caller learns N' while k_group_mean still runs.
+// The bookkeeping slots (nodes, candidates, edges, iterations) stay device-side: they are diagnostics, added with
+// fire-and-forget atomics that nobody waits for, and are complete once the stream has drained.
+__device__ __forceinline__ void publish_counts(const TemporalArgs& a, int n_out, int overflow) {
     a.counts[STTM_CNT_OUT] = n_out;
+    if (overflow) atomicAdd(a.counts + STTM_CNT_OVERFLOW, overflow);
     if (a.counts_host) {
-        // straight into pinned host memory: the caller learns N' while k_group_mean still runs
-        for (int i = 0; i < STTM_CNT_SLOTS - 1; ++i)
-            __hip_atomic_store(a.counts_host + i, i == STTM_CNT_OUT ? n_out : ld_agent(a.counts + i), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(a.counts_host + STTM_CNT_OUT, n_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(a.counts_host + STTM_CNT_OVERFLOW, overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(a.counts_host + STTM_CNT_SLOTS - 1, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
@@ -265,32 +267,45 @@ __device__ __forceinline__ bool column_labels(const TemporalArgs& a, int r, cons
     int* rawd = arr.rep; int* raws = arr.rep2;
     const int nf = a.T - 1;
     int E = 0, nact = 0, K = 0;
-    int cand_pre = 0;
+    int cand_pre = 0, ovf = 0;
     STTM_LBL_TICK(0);
+    // Loads that are consumed much later are issued first: the node counts of this column's (frame, root cell) lists, the
+    // candidate counts (bookkeeping), the sticky overflow flag of the pair kernel.
+    const unsigned head_pre = tid < a.T ? (unsigned)a.rc_list[(int64_t)(tid * R + r) * a.rc_stride] : 0u;
+    if (temporal)
+        for (int t = tid; t < nf; t += nt) cand_pre += ld_agent(a.cand_cnt + (int64_t)r * nf + t);
+    if (tid == 0) ovf = ld_agent(a.bar + 1);
     for (int t = tid; t < a.T; t += nt) cst<GMEM>(dec + t, 0);
     if (temporal) {
         // ---- this column's kept edges -> raw (slot, slot) pairs + the bitmask of active slots ------------------------------
-        const int cap = a.ecap, total = nf * cap;
+        const int cap = a.ecap;
         const int32_t* elist = a.edges + (int64_t)r * nf * cap;
         const int32_t* ecnt = a.edge_cnt + (int64_t)r * nf;
         for (int w = tid; w < W; w += nt) cst<GMEM>(bits + w, 0);
         if (tid == 0) sh->ecount = 0;
         col_sync<GMEM>();
-        constexpr int PER = 8;
+        auto take = [&](int t, int packed, int pos) {
+            const unsigned w = (unsigned)packed;
+            const int sd = t * col.A + (int)(w >> 16), ss = (t + 1) * col.A + (int)(w & 0xffffu);
+            if (pos < arr.cap) { cst<GMEM>(rawd + pos, sd); cst<GMEM>(raws + pos, ss); }
+            caor<GMEM>(bits + (sd >> 5), (int)(1u << (sd & 31)));
+            caor<GMEM>(bits + (ss >> 5), (int)(1u << (ss & 31)));
+        };
+        // ONE round trip: the length of every pair's list together with its first HEAD entries (a list holds two edges on
+        // average; entries past the length are stale).  The thread that reads entry 0 of a longer list walks the rest.
+        constexpr int HEAD = 8, PER = 2;
+        const int total = nf * HEAD;
         for (int j0 = 0; j0 < total; j0 += PER * nt) {
-            int val[PER], tt[PER];
+            int val[PER], tt[PER], cn[PER];
             bool ok[PER];
-            // independent loads, one round trip: every entry together with the length of its list (entries past the
-            // length are stale)
 #pragma unroll
             for (int k = 0; k < PER; ++k) {
                 const int j = j0 + k * nt + tid;
                 const bool in = j < total;
-                const int t = in ? (int)__umulhi((unsigned)j, a.ecap_magic) : 0;
-                const int e = j - t * cap;
-                val[k] = in ? ld_agent(elist + j) : 0;
-                const int cn = in ? ld_agent(ecnt + t) : 0;
-                ok[k] = in && e < cn;
+                const int t = j / HEAD, e = j % HEAD;
+                val[k] = (in && e < cap) ? ld_agent(elist + (int64_t)t * cap + e) : 0;
+                cn[k] = in ? ld_agent(ecnt + t) : 0;
+                ok[k] = in && e < cn[k];
                 tt[k] = t;
             }
             int nv = 0;
@@ -308,17 +323,16 @@ __device__ __forceinline__ bool column_labels(const TemporalArgs& a, int r, cons
             base = __shfl(base, 63, 64);
             int pos = base + incl - nv;
 #pragma unroll
+            for (int k = 0; k < PER; ++k)
+                if (ok[k]) take(tt[k], val[k], pos++);
+#pragma unroll
             for (int k = 0; k < PER; ++k) {
-                if (!ok[k]) continue;
-                const unsigned w = (unsigned)val[k];
-                const int sd = tt[k] * col.A + (int)(w >> 16), ss = (tt[k] + 1) * col.A + (int)(w & 0xffffu);
-                if (pos < arr.cap) { cst<GMEM>(rawd + pos, sd); cst<GMEM>(raws + pos, ss); }
-                ++pos;
-                caor<GMEM>(bits + (sd >> 5), (int)(1u << (sd & 31)));
-                caor<GMEM>(bits + (ss >> 5), (int)(1u << (ss & 31)));
+                const int j = j0 + k * nt + tid;
+                if (j < total && j % HEAD == 0 && cn[k] > HEAD)
+                    for (int e = HEAD; e < cn[k] && e < cap; ++e)
+                        take(tt[k], ld_agent(elist + (int64_t)tt[k] * cap + e), atomicAdd(&sh->ecount, 1));
             }
         }
-        for (int t = tid; t < nf; t += nt) cand_pre += ld_agent(a.cand_cnt + (int64_t)r * nf + t);
         col_sync<GMEM>();
         E = sh->ecount;
         STTM_LBL_TICK(1);
@@ -374,14 +388,17 @@ __device__ __forceinline__ bool column_labels(const TemporalArgs& a, int r, cons
         if (tid == 0) {
             mask |= ~0ull << (it - 1);           // the labels no longer move: every later iteration is idempotent
             __hip_atomic_store(a.col_mask + r, mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (overflow) atomicAdd(a.counts + STTM_CNT_OVERFLOW, 1);
+            if (overflow) ovf += 1;
         }
         probe_iters = it;
     }
     if constexpr (MODE == COL_PROBE) return true;
     STTM_LBL_TICK(3);
     bool alive = true;
-    if constexpr (MODE == COL_FUSED) alive = grid_barrier(a.bar + 0, R, a.counts + STTM_CNT_OVERFLOW, &sh->ok);
+    if constexpr (MODE == COL_FUSED) {
+        alive = grid_barrier(a.bar + 0, R, &sh->ok);
+        if (!alive) ovf += 1;
+    }
     STTM_LBL_TICK(4);
     int nodes = 0, leafnodes = 0, survivors = 0;
     if (alive) {
@@ -429,18 +446,18 @@ __device__ __forceinline__ bool column_labels(const TemporalArgs& a, int r, cons
         // survivors per frame -> frame_cnt (one atomic per (frame, column)); the group-mean kernel turns them into row
         // prefixes.  The spatial kernel left the node count (and the 1x1 count) of every (frame, root cell) in its list head.
         for (int t = tid; t < a.T; t += nt) {
-            const unsigned head = (unsigned)a.rc_list[(int64_t)(t * R + r) * a.rc_stride];
+            const unsigned head = t == tid ? head_pre : (unsigned)a.rc_list[(int64_t)(t * R + r) * a.rc_stride];
             const int n_t = (int)(head & 0xffffu), c = n_t - cld<GMEM>(dec + t);
             nodes += n_t; leafnodes += (int)(head >> 16); survivors += c;
             if (c) atomicAdd(a.frame_cnt + t, c);
         }
         STTM_LBL_TICK(7);
     }
-    // ---- bookkeeping counters and N'.  The per-wave partials meet in LDS; thread 0 adds this column's totals to the
-    // global counters, waits for exactly those atomics, and then adds (survivors << 24 | 1) to ONE 64-bit word
-    // (R < 2^24 columns, N' < 2^31): the add that completes the arrival count also returns the complete N', so the
-    // last column publishes everything to the host with no second grid barrier and no drain of the other threads'
-    // stores (their consumer is the next kernel).
+    // ---- N' and the bookkeeping counters.  The per-wave partials meet in LDS; thread 0 adds (survivors << 24 | 1) -- plus
+    // this column's overflow events in the top byte -- to ONE 64-bit word (R < 2^24 columns, N' < 2^31): the add that
+    // completes the arrival count also returns the complete N', so the last column publishes it to the host with no second
+    // grid barrier and no drain of anybody's stores (their consumer is the next kernel).  The diagnostic counters are
+    // fire-and-forget atomics.
     int cand = temporal ? cand_pre : 0;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -454,16 +471,18 @@ __device__ __forceinline__ bool column_labels(const TemporalArgs& a, int r, cons
         for (int w = 0; w < nwave; ++w)
 #pragma unroll
             for (int k = 0; k < 4; ++k) tot[k] += sh->part[k][w];
+        unsigned long long* word = reinterpret_cast<unsigned long long*>(a.bar + 2);
+        const unsigned long long mine = ((unsigned long long)(ovf > 127 ? 127 : ovf) << 56) | ((unsigned long long)(unsigned)tot[2] << 24) | 1ull;
+        const unsigned long long old = __hip_atomic_fetch_add(word, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tot[0]) atomicAdd(a.counts + STTM_CNT_NODES, tot[0]);
         if (tot[1]) atomicAdd(a.counts + STTM_CNT_LEAFNODES, tot[1]);
         if (tot[3]) atomicAdd(a.counts + STTM_CNT_CANDIDATES, tot[3]);
         if (E) atomicAdd(a.counts + STTM_CNT_EDGES, E);
         if (r == 0) st_agent(a.counts + STTM_CNT_ITERS, K);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned long long* word = reinterpret_cast<unsigned long long*>(a.bar + 2);
-        const unsigned long long old = __hip_atomic_fetch_add(word, ((unsigned long long)(unsigned)tot[2] << 24) | 1ull,
-                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((int)(old & 0xffffffull) == R - 1) publish_counts(a, (int)(old >> 24) + tot[2]);
+        if ((int)(old & 0xffffffull) == R - 1) {
+            const unsigned long long all = old + mine;
+            publish_counts(a, (int)((all >> 24) & 0xffffffffull), (int)(all >> 56));
+        }
     }
     STTM_LBL_TICK(8);
     return true;
@@ -555,7 +574,19 @@ __global__ void __launch_bounds__(1024) k_pairs(const TemporalArgs a0, const Bat
 #define STTM_K2_TICK(n) STTM_DEV_TICK(a.dev, k2_ticks, blockIdx.x == a.dev.k2_wg, n)
     STTM_K2_TICK(0);
     const int L = a.pairs_seg, nf = a.T - 1, nseg = (nf + L - 1) / L;
-    const int r = blockIdx.x / nseg, sg = blockIdx.x - r * nseg;
+    // XCD-aware order of the runs.  Workgroup ids go round-robin over the 8 XCDs, each with its own L2, and the node rows of a
+    // frame are read by the run that ends with it and by the run that starts with it: keep kXcdRuns consecutive runs of one
+    // root cell on ONE XCD so that the second read hits that L2 instead of going to the fabric again (measured with
+    // one-pair runs: 19.2 -> 16.0 us, fetch 76 -> 68 MB).
+    constexpr int kXcdRuns = 16;
+    const int total_runs = a.R * nseg;
+    int q;
+    {
+        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+        q = ((i / kXcdRuns) * 8 + xcd) * kXcdRuns + i % kXcdRuns;
+    }
+    if (q >= total_runs) return;
+    const int r = q / nseg, sg = q - r * nseg;
     const int t0 = sg * L, np = nf - t0 < L ? nf - t0 : L;           // this workgroup: pairs t0 .. t0 + np - 1
     const int R = a.R, cap = a.ecap, HW = a.H * a.W;
     PairShared* ps = reinterpret_cast<PairShared*>(smem_raw);
@@ -644,7 +675,8 @@ __global__ void __launch_bounds__(1024) k_pairs(const TemporalArgs a0, const Bat
         const int64_t cidx = (int64_t)r * nf + (t0 + cd.p);          // column-major: a column's lists are contiguous
         const int* lA = lists + cd.p * a.rc_stride;
         if (a.edge_sim) a.edge_sim[cidx * cap + e] = sim;
-        st_agent(a.edges + cidx * cap + e, (int)((leaf_of(lA, cd.k >> 16) << 16) | leaf_of(lA + a.rc_stride, cd.k & 0xffff)));
+        const int packed = (int)((leaf_of(lA, cd.k >> 16) << 16) | leaf_of(lA + a.rc_stride, cd.k & 0xffff));
+        if (a.fold_labels) st_agent(a.edges + cidx * cap + e, packed); else a.edges[cidx * cap + e] = packed;
     };
     if (a.n_head > 0) {
         // per-head cosine, averaged over heads (quadtree_temporal_merger.py:65-68): G adjacent lanes own one head
@@ -715,16 +747,16 @@ __global__ void __launch_bounds__(1024) k_pairs(const TemporalArgs a0, const Bat
             if (sim >= a.temporal_thresh) keep(lane ? q1 : q0, sim);
         }
     }
-    // every wave's edge stores have left before the counts say they are there
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (folded label stage: every wave's edge stores have left before the counts say they are there)
+    if (a.fold_labels) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     STTM_K2_TICK(2);
     if (wave == 0) {
         if (lane < np) {
             const int64_t cidx = (int64_t)r * nf + (t0 + lane);
-            st_agent(a.edge_cnt + cidx, nkept[lane]);
-            st_agent(a.cand_cnt + cidx, ncand[lane]);
-            if (ncand[lane] > cap) atomicAdd(a.counts + STTM_CNT_OVERFLOW, 1);     // cannot happen: nested-or-disjoint boxes give < 2A pairs
+            if (a.fold_labels) { st_agent(a.edge_cnt + cidx, nkept[lane]); st_agent(a.cand_cnt + cidx, ncand[lane]); }
+            else { a.edge_cnt[cidx] = nkept[lane]; a.cand_cnt[cidx] = ncand[lane]; }
+            if (ncand[lane] > cap) st_agent(a.bar + 1, 1);     // sticky overflow flag; cannot happen: nested-or-disjoint boxes give < 2A pairs
         }
         if (a.fold_labels) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -752,7 +784,7 @@ static size_t pairs_smem(const TemporalArgs& a) {
 hipError_t launch_pairs(const TemporalArgs& a, const BatchPtrs& bp, int n_videos, hipStream_t stream) {
     if (a.T < 2) return hipSuccess;
     const int nseg = (a.T - 1 + a.pairs_seg - 1) / a.pairs_seg;
-    const int grid = a.R * nseg;
+    const int grid = (a.R * nseg + 127) / 128 * 128;                  // whole (8 XCDs x 16 runs) chunks of the XCD-aware order
     size_t smem = pairs_smem(a);
     if (a.fold_labels) {
         const size_t lb = col_lds_bytes(a.fold_cap, a.max_slots, a.T);
@@ -771,17 +803,21 @@ hipError_t launch_pairs(const TemporalArgs& a, const BatchPtrs& bp, int n_videos
     return hipGetLastError();
 }
 
-// frame pairs per pair workgroup and its block size: about one workgroup per CU (the runs of all columns then run side by
-// side in one round), 128 threads per pair of the run, 256 .. 1024 threads
-void pairs_shape(int T, int R, int n_videos, int want_seg, int want_nt, int* seg, int* nt) {
+// Frame pairs per pair workgroup (a run) and its block size.  Default: one pair per 256-thread workgroup -- the most
+// workgroups in flight, measured fastest for the pair phase (T=128 headline: 1 pair x 256 threads 15.3 us; runs of 4 / 8
+// pairs with 512 / 1024 threads 18-19 us: a CU with one big workgroup streams its rows at the per-CU rate).  Runs are for
+// the folded label stage (about one workgroup per CU, so the whole grid is resident) and for experiments.
+void pairs_shape(int T, int R, int fold, int want_seg, int want_nt, int* seg, int* nt) {
     const int nf = T > 1 ? T - 1 : 1;
-    int cus = device_cus_or(256);
-    long cells = (long)nf * R * n_videos;
-    int L = want_seg > 0 ? want_seg : (int)((cells + cus - 1) / cus);
+    int L = want_seg > 0 ? want_seg : 1;
+    if (want_seg <= 0 && fold) {
+        const int cus = device_cus_or(256);
+        L = (int)(((long)nf * R + cus - 1) / cus);
+    }
     if (L < 1) L = 1;
-    if (L > 16) L = 16;
+    if (L > 64) L = 64;
     if (L > nf) L = nf;
-    int n = want_nt > 0 ? want_nt : 128 * L;
+    int n = want_nt > 0 ? want_nt : (L == 1 ? 256 : 128 * L);
     const int lo = want_nt > 0 ? 64 : 256;
     if (n < lo) n = lo;
     if (n > 1024) n = 1024;
@@ -791,15 +827,19 @@ void pairs_shape(int T, int R, int n_videos, int want_seg, int want_nt, int* seg
     *seg = L; *nt = p2;
 }
 
-
-// Fold the label stage into the pair kernel when (a) there is a pair kernel and no slow_ver filter between the two, (b) the
+// OPT-IN ("fold_labels" switch; measured no faster than the stand-alone label kernel on the headline -- DESIGN.md -- and prone to
+// barrier stalls when several streams run it at once): fold the label stage into the pair kernel when (a) there is a pair kernel and no slow_ver filter between the two, (b) the
 // column's active nodes get a useful amount of LDS, and (c) the R * n_videos workgroups that wait for each other at the
 // in-kernel grid barrier occupy at most half of the CUs (a 1024-thread workgroup can take a CU for itself), so every other
 // workgroup of the launch still finds a CU and runs to completion.
 bool labels_can_fold(const TemporalArgs& a, int n_videos, int* cap) {
-    if (a.no_fold || a.slow_ver || !(a.temporal_thresh > 0.f) || a.T < 2) return false;
+    if (!a.want_fold || a.slow_ver || !(a.temporal_thresh > 0.f) || a.T < 2) return false;
     const int cus = device_cus();
     if (cus <= 0 || (long long)a.R * n_videos > cus / 2) return false;
+    // ... and the whole pair grid runs in ONE round (a workgroup of 512+ threads has a CU to itself): grids of several
+    // rounds were seen to stall at the barrier, so they take the stand-alone label kernel
+    const int nseg = (a.T - 1 + a.pairs_seg - 1) / a.pairs_seg;
+    if ((long long)a.R * nseg * n_videos > (long long)cus * (a.pairs_nt >= 512 ? 1 : 2)) return false;
     const size_t budget = (size_t)a.fold_kb * 1024;
     const size_t fixed = col_lds_bytes(0, a.max_slots, a.T);
     if (fixed + 16 * 256 > budget) return false;
@@ -1096,12 +1136,14 @@ __global__ void __launch_bounds__(256, TypeInfo<T>::lowp ? 6 : 8) k_group_mean(c
                         for (int sb = slot0 + 1; found < n - 1 && sb < col.slots; sb += 64) {
                             const int sl = sb + lane;
                             const int mrow = sl < col.slots ? slot_to_row(a, col, sl) : -1;
-                            const bool hit = mrow >= 0 && a.lab_row[mrow] == origin;
+                            // label and box of every scanned slot in the same round trip (the box is only needed for hits)
+                            const int lab = mrow >= 0 ? a.lab_row[mrow] : -1;
+                            const uint32_t q = mrow >= 0 ? a.meta[mrow] : 0u;
+                            const bool hit = lab == origin;
                             unsigned long long mm = __ballot(hit);
                             if (mm == 0ull) continue;
                             int ar = 0;
                             if (hit) {
-                                const uint32_t q = a.meta[mrow];
                                 const int rem = mrow - slot_frame(col, sl) * HW;
                                 const int my1 = rem / a.W, mx1 = rem - my1 * a.W;
                                 ar = ((int)(q >> 16) - my1) * ((int)(q & 0xffff) - mx1);

@@ -97,7 +97,9 @@ def _wait(lib, host_row, seq, stream, counts_row):
 
 def quadtree_merge_raw(x, threshold, temporal_thresh, root_level, weighted_avg, head_dim, slow_ver=False, return_ctx=False,
                        feat_dest=None, events=None):
-    """Launch the merge of one video and return the worst-case-sized outputs plus the host counts.
+    """Launch the merge of one video and return the worst-case-sized outputs plus the host counts (only the slots CNT_OUT and
+    CNT_OVERFLOW of the host mirror are published early; the diagnostic counters stay in the device `counts` tensor of the
+    returned context and are complete once the stream has drained).
     x: logical [T, C, H, W] CUDA tensor (any strides; channels-last views run zero-copy).
     events: optional _lib.KernelEvents -- the library records them around its kernels (per-kernel timing)."""
     if not x.is_cuda:

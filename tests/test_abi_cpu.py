@@ -124,7 +124,7 @@ def test_host_side_size_functions_of_the_baselines():
 
 def test_configure_accepts_known_keys_only():
     lib = _lib.load()
-    assert lib.sttm_configure(b"no_fold", 0) == 0 and lib.sttm_configure(b"fold_kb", 20) == 0
+    assert lib.sttm_configure(b"fold_labels", 0) == 0 and lib.sttm_configure(b"fold_kb", 20) == 0
     assert lib.sttm_configure(b"does_not_exist", 1) == _lib.ERR_ARG
     assert "does_not_exist" in _lib.last_error()
 

@@ -64,7 +64,9 @@ def test_dycoke_interface_behaviour():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         dycoke_ttm(torch.randn(6 * 9, 8), 6, 0.7)
     with pytest.raises(NotImplementedError):
-        dycoke_ttm(torch.randn(6 * 9, 8, device=DEV).bfloat16(), 6, 0.7)
+        dycoke_ttm(torch.randn(6 * 9, 8, device=DEV).double(), 6, 0.7)           # float32 / bfloat16 / float16 only
+    o16, i16 = dycoke_ttm(torch.randn(6 * 9, 8, device=DEV).bfloat16(), 6, 0.7)
+    assert o16.dtype == torch.bfloat16 and o16.shape[0] == i16.shape[0]
     # ties (identical tokens everywhere): smaller token id first, and the output is still well formed
     x = torch.ones(6 * 9, 8, device=DEV)
     out, idx = dycoke_ttm(x, 6, 0.5)

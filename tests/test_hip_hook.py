@@ -191,3 +191,58 @@ def test_patched_qwen2vl_text_model_runs_on_device(pattern):
         assert torch.allclose(out, ref, atol=2e-5)
     finally:
         MPI.restore_qwen2()
+
+
+@pytest.mark.parametrize("pattern", ["tome", "dycoke-stage1", "quadtree"])
+def test_hooks_on_a_bf16_model(pattern):
+    """The production dtype: LLaVA-Video / Qwen2-VL checkpoints run bf16 hidden states (eval_vidqa_by_feat_llavavideo.py:104), and
+    that is what the installed hooks hand to get_tome_features / dycoke_ttm / get_quadtree_features.  (a) the patched bf16
+    Qwen2Model runs end to end on the GPU; (b) the hook's merge on the bf16 hidden states agrees with the oracle on the same
+    tensor: ToMe ratio 0.5 keeps exactly the odd tokens (ids equal), DyCoke / quadtree ids as reported."""
+    pytest.importorskip("transformers")
+    from transformers import Qwen2Config
+    from transformers.models.qwen2.modeling_qwen2 import Qwen2Model
+    from oracle import dycoke_oracle as D
+    from oracle import sttm_oracle as O
+    from sttm_amd import monkey_patch_interface as MPI
+    from sttm_amd import get_quadtree_features, get_tome_features, patch_hooks
+    from sttm_amd.dycoke_merger import dycoke_ttm
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    C, T, H = 128, 6, 14
+    cfg = Qwen2Config(vocab_size=64, hidden_size=C, intermediate_size=256, num_hidden_layers=3, num_attention_heads=4,
+                      num_key_value_heads=2, max_position_embeddings=4096, attn_implementation="sdpa")
+    model = Qwen2Model(cfg).eval().to(dev, torch.bfloat16)
+    hs, start, length = _prompt(T, C, H, H, torch.bfloat16, seed=31)
+    pos = torch.arange(hs.shape[1], device=dev).unsqueeze(0)
+    kw = {"quadtree": dict(sa_tree_thresh=0.85, sa_tree_temporal_thresh=0.55, sa_tree_root_level=1),
+          "dycoke-stage1": dict(sa_prune_ratio=0.7), "tome": dict(sa_prune_ratio=0.5, sa_tome_ver="video")}[pattern]
+    try:
+        MPI.replace_qwen2_by_sparse_attn(pattern, sa_start_layer_idx=1, **kw)
+        model.image_token_start_index = torch.tensor(start)
+        model.image_token_length = torch.tensor(length)
+        model.num_frame = torch.tensor(T)
+        with torch.inference_mode():
+            out = model(inputs_embeds=hs, use_cache=False).last_hidden_state
+        assert out.dtype == torch.bfloat16 and out.shape[1] < hs.shape[1] and bool(torch.isfinite(out.float()).all())
+        # the merge itself, on the same bf16 tensor, device vs oracle
+        if pattern == "tome":
+            hm, _, tok = patch_hooks.tome_merge(hs, pos, start, length, T, get_tome_features, 0.5, "video")
+            rm, _, rtok = patch_hooks.tome_merge(hs.cpu(), pos.cpu(), start, length, T, O.get_tome_features, 0.5, "video")
+            assert torch.equal(tok.cpu(), rtok) and hm.shape == rm.shape
+            rel = (hm.cpu().float() - rm.float()).abs() / rm.float().abs().clamp_min(1.0)
+            assert float((rel > 2.0 ** -6).any(dim=-1).float().mean()) <= 0.03
+            assert out.shape[1] == hm.shape[1]
+        elif pattern == "dycoke-stage1":
+            hm, _, idx = patch_hooks.dycoke_merge(hs, pos, start, length, T, dycoke_ttm, 0.7)
+            rm, _, ridx = patch_hooks.dycoke_merge(hs.cpu(), pos.cpu(), start, length, T, D.dycoke_ttm, 0.7)
+            assert hm.shape == rm.shape and out.shape[1] == hm.shape[1]
+            agree = len(set(idx.cpu().tolist()) & set(ridx.tolist())) / len(ridx)
+            print(f"dycoke-stage1 on bf16: kept-token agreement {agree:.4f}")
+            assert agree >= 0.9                                         # bf16 similarities tie at the cut; see test_hip_dycoke.py
+        else:
+            hm, _, idx = patch_hooks.quadtree_merge_llava(hs, pos, start, length, T, get_quadtree_features, 0.85, 0.55, 1, False)
+            rm, _, ridx = patch_hooks.quadtree_merge_llava(hs.cpu(), pos.cpu(), start, length, T, O.get_quadtree_features, 0.85, 0.55, 1, False)
+            assert torch.equal(idx.cpu(), ridx) and out.shape[1] == hm.shape[1]
+    finally:
+        MPI.restore_qwen2()

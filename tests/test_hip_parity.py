@@ -156,12 +156,14 @@ def test_slow_ver_against_oracle(T, C, H, W, seed, kind):
 
 
 LABEL_PATHS = [
-    dict(no_fold=1),                                 # stand-alone fused label kernel (in-kernel grid barrier)
-    dict(no_fold=1, no_fuse=1),                      # stand-alone label stage as two launches (probe, final)
-    dict(force_gmem_labels=1),                       # folded into the pair kernel, column arrays in global scratch
-    dict(no_fold=1, force_gmem_labels=1),            # stand-alone, global scratch (the path of columns too large for LDS)
-    dict(no_fold=1, no_fuse=1, force_gmem_labels=1),
-    dict(fold_kb=8),                                 # folded with a tiny LDS budget: busy columns overflow to global scratch in-kernel
+    dict(),                                          # default: stand-alone fused label kernel (in-kernel grid barrier)
+    dict(no_fuse=1),                                 # stand-alone label stage as two launches (probe, final)
+    dict(fold_labels=1, force_gmem_labels=1),        # folded into the pair kernel, column arrays in global scratch
+    dict(force_gmem_labels=1),                       # stand-alone, global scratch (the path of columns too large for LDS)
+    dict(no_fuse=1, force_gmem_labels=1),
+    dict(fold_labels=1),                             # label stage folded into the pair kernel (runs of frame pairs, last arriver)
+    dict(fold_labels=1, fold_kb=8),                  # ... with a tiny LDS budget: busy columns overflow to global scratch in-kernel
+    dict(pairs_seg=4), dict(pairs_seg=16, pairs_nt=256),   # runs of frame pairs per pair workgroup
 ]
 
 
@@ -172,7 +174,7 @@ def test_label_stage_paths_give_identical_results(opts):
     from oracle import sttm_oracle as O
     from sttm_amd import _lib, get_quadtree_features
     from sttm_amd.synth import synth_video
-    defaults = dict(no_fold=0, no_fuse=0, force_gmem_labels=0, fold_kb=64)
+    defaults = dict(fold_labels=0, no_fuse=0, force_gmem_labels=0, fold_kb=64, pairs_seg=0, pairs_nt=0)
     try:
         _lib.configure(**opts)
         for path in case_paths(["st_"]):

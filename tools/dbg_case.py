@@ -10,8 +10,8 @@ T, C, H, W, seed = [int(v) for v in (sys.argv[1:6] + [1024, 32, 14, 14, 20][len(
 x = synth_video(T, C, H, W, seed=seed)
 ef, en, et = O.get_quadtree_features(x, 0.85, 0.55, 1)
 xd = x.to("cuda:0")
-for opts in [dict(no_fold=1), dict(), dict(fold_kb=150), dict(force_gmem_labels=1), dict(no_fold=1, force_gmem_labels=1), dict(pairs_seg=4), dict(pairs_seg=16, pairs_nt=256)]:
-    base = dict(no_fold=0, no_fuse=0, force_gmem_labels=0, fold_kb=64, pairs_seg=0, pairs_nt=0)
+for opts in [dict(), dict(fold_labels=1), dict(fold_labels=1, fold_kb=150), dict(force_gmem_labels=1), dict(fold_labels=1, force_gmem_labels=1), dict(pairs_seg=4), dict(pairs_seg=16, pairs_nt=256)]:
+    base = dict(fold_labels=0, no_fuse=0, force_gmem_labels=0, fold_kb=64, pairs_seg=0, pairs_nt=0)
     base.update(opts)
     _lib.configure(**base)
     try:
