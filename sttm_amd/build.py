@@ -15,7 +15,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsttm_hip.so")
 SOURCES = ["quadtree_spatial.hip", "spatial_f32.hip", "spatial_bf16.hip", "spatial_f16.hip", "spatial_f32_head.hip",
            "spatial_bf16_head.hip", "spatial_f16_head.hip", "temporal_merge.hip", "tome.hip", "pool2d.hip", "dycoke.hip", "octree.hip", "api.hip"]
-HEADERS = ["sttm_common.h", "sttm_kernels.h", "quadtree_spatial.inc", os.path.join("..", "..", "include", "sttm_hip.h")]
+HEADERS = ["sttm_common.h", "sttm_kernels.h", "sttm_pairs.inc", "quadtree_spatial.inc", os.path.join("..", "..", "include", "sttm_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 if os.environ.get("STTM_NT_STREAM") == "1":
     FLAGS.append("-DSTTM_NT_STREAM")

@@ -27,6 +27,7 @@
 #include <cstdlib>
 
 #include "sttm_kernels.h"
+#include "sttm_pairs.inc"
 
 namespace sttm {
 
@@ -588,183 +589,22 @@ __global__ void __launch_bounds__(1024) k_pairs(const TemporalArgs a0, const Bat
     if (q >= total_runs) return;
     const int r = q / nseg, sg = q - r * nseg;
     const int t0 = sg * L, np = nf - t0 < L ? nf - t0 : L;           // this workgroup: pairs t0 .. t0 + np - 1
-    const int R = a.R, cap = a.ecap, HW = a.H * a.W;
     PairShared* ps = reinterpret_cast<PairShared*>(smem_raw);
-    int* ncand = reinterpret_cast<int*>(smem_raw + sizeof(PairShared));   // [L]
-    int* nkept = ncand + L;                                               // [L]
-    int* lists = nkept + L;                                               // [L + 1][rc_stride] node lists of frames t0 .. t0 + np
-    int* cand = lists + (L + 1) * a.rc_stride;                            // [L][cap] packed (ia << 16 | ib)
     const Column col = make_column(a, g, r);
-    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = nt >> 6;
-    // ONE round trip for the counts and the node boxes of every frame of the run: each list entry is fetched speculatively
-    // (entries past the count are stale but inside the row) and parked in LDS for the box tests
-    for (int i = tid; i < (np + 1) * a.rc_stride; i += nt) {
-        const int f = i / a.rc_stride, e = i - f * a.rc_stride;
-        lists[i] = a.rc_list[(int64_t)((t0 + f) * R + r) * a.rc_stride + e];
-    }
-    if (tid < L) { ncand[tid] = 0; nkept[tid] = 0; }
+    const PairGeo geo = {col.Y1, col.X1, col.aw};
+    PairArgs pa;
+    pa.T = a.T; pa.H = a.H; pa.W = a.W; pa.C = a.C; pa.R = a.R;
+    pa.temporal_thresh = a.temporal_thresh; pa.n_head = a.n_head; pa.head_lanes = a.head_lanes; pa.inline_norms = a.inline_norms;
+    pa.S = a.S; pa.xrows = a.xrows; pa.inrm = a.inrm; pa.rc_list = a.rc_list; pa.rc_stride = a.rc_stride;
+    pa.edges = a.edges; pa.edge_sim = a.edge_sim; pa.edge_cnt = a.edge_cnt; pa.cand_cnt = a.cand_cnt; pa.ecap = a.ecap; pa.bar = a.bar;
+    const int tid = threadIdx.x;
     if (tid == 0) ps->last = 0;
-    __syncthreads();
-    {
-        // box tests: the threads are split evenly over the pairs (tpp each, a power of two); inside a pair they walk an
-        // (ia, ib) grid whose width is the power of two >= nB, so no integer division per test
-        int lp2 = 0;
-        while ((1 << lp2) < L) ++lp2;
-        const int tpp = nt >> lp2, p = tid >> (31 - __clz(tpp)), lt = tid & (tpp - 1);
-        if (p < np) {
-            const int* listA = lists + p * a.rc_stride;
-            const int* listB = listA + a.rc_stride;
-            const int nA = listA[0] & 0xffff, nB = listB[0] & 0xffff;
-            int lg = 0;
-            while ((1 << lg) < nB) ++lg;
-            auto test = [&](int ia, int ib) {
-                const unsigned ba = (unsigned)listA[1 + ia], bb = (unsigned)listB[1 + ib];
-                const int ay1 = ba >> 24, ax1 = (ba >> 16) & 255, ay2 = (ba >> 8) & 255, ax2 = ba & 255;
-                const int by1 = bb >> 24, bx1 = (bb >> 16) & 255, by2 = (bb >> 8) & 255, bx2 = bb & 255;
-                const bool a_has_b = ay1 <= by1 && ax1 <= bx1 && ay2 >= by2 && ax2 >= bx2;
-                const bool b_has_a = ay1 >= by1 && ax1 >= bx1 && ay2 <= by2 && ax2 <= bx2;
-                if (a_has_b || b_has_a) {
-                    const int pos = atomicAdd(&ncand[p], 1);
-                    if (pos < cap) cand[p * cap + pos] = (ia << 16) | ib;
-                }
-            };
-            if ((1 << lg) <= tpp) {
-                const int ib = lt & ((1 << lg) - 1);
-                if (ib < nB)
-                    for (int ia = lt >> lg; ia < nA; ia += tpp >> lg) test(ia, ib);
-            } else {                                          // more nodes in the cell than threads per pair: plain loop
-                for (int q = lt; q < nA * nB; q += tpp) { const int ia = q / nB; test(ia, q - ia * nB); }
-            }
-        }
-    }
-    __syncthreads();
-    STTM_K2_TICK(1);
-    // flat work list over the run's candidates: entry c belongs to the pair p with base(p) <= c < base(p + 1)
-    int total = 0;
-    for (int p = 0; p < np; ++p) total += ncand[p] < cap ? ncand[p] : cap;
-    struct Cand { int p, k; };
-    auto locate = [&](int c) {
-        Cand o; o.p = 0;
-        int base = 0;
-        while (o.p < np - 1) {
-            const int n = ncand[o.p] < cap ? ncand[o.p] : cap;
-            if (c < base + n) break;
-            base += n; ++o.p;
-        }
-        o.k = cand[o.p * cap + (c - base)];
-        return o;
-    };
-    auto row_of = [&](const int* Lst, int i, int frame) {
-        const unsigned b = (unsigned)Lst[1 + i];
-        return frame * HW + (int)(b >> 24) * a.W + (int)((b >> 16) & 255);
-    };
-    // offset of a list entry's origin leaf inside the root cell, straight from its box
-    auto leaf_of = [&](const int* Lst, int i) {
-        const unsigned b = (unsigned)Lst[1 + i];
-        return (unsigned)(((int)(b >> 24) - col.Y1) * col.aw + ((int)((b >> 16) & 255) - col.X1));
-    };
-    auto src_of = [&](const int* Lst, int i) -> const void* {      // 1x1 nodes were not copied out of x
-        const unsigned b = (unsigned)Lst[1 + i];
-        const bool leaf = ((b >> 8) & 255) - (b >> 24) == 1 && (b & 255) - ((b >> 16) & 255) == 1;
-        return (leaf && a.xrows) ? a.xrows : a.S;
-    };
-    // kept edges are published with agent-scope (write-through) stores: their reader may be another workgroup of
-    // this launch (the column's last arriver), possibly on another XCD
-    auto keep = [&](const Cand& cd, float sim) {
-        const int e = atomicAdd(&nkept[cd.p], 1);
-        const int64_t cidx = (int64_t)r * nf + (t0 + cd.p);          // column-major: a column's lists are contiguous
-        const int* lA = lists + cd.p * a.rc_stride;
-        if (a.edge_sim) a.edge_sim[cidx * cap + e] = sim;
-        const int packed = (int)((leaf_of(lA, cd.k >> 16) << 16) | leaf_of(lA + a.rc_stride, cd.k & 0xffff));
-        if (a.fold_labels) st_agent(a.edges + cidx * cap + e, packed); else a.edges[cidx * cap + e] = packed;
-    };
-    if (a.n_head > 0) {
-        // per-head cosine, averaged over heads (quadtree_temporal_merger.py:65-68): G adjacent lanes own one head
-        const int G = a.head_lanes;
-        for (int c = wave; c < total; c += nwave) {
-            const Cand cd = locate(c);
-            const int* lA = lists + cd.p * a.rc_stride; const int* lB = lA + a.rc_stride;
-            const int rowA = row_of(lA, cd.k >> 16, t0 + cd.p), rowB = row_of(lB, cd.k & 0xffff, t0 + cd.p + 1);
-            const void* sA = src_of(lA, cd.k >> 16); const void* sB = src_of(lB, cd.k & 0xffff);
-            float acc = 0.f;
-            for (int base = 0; base < a.C; base += 64 * VEC) {
-                const int c0 = base + lane * VEC;
-                float d = 0.f, na = 0.f, nb = 0.f;
-                if (c0 < a.C) {
-                    const Pack<T, VEC> pa = load_pack<T, VEC>(sA, (int64_t)rowA * a.C + c0);
-                    const Pack<T, VEC> pb = load_pack<T, VEC>(sB, (int64_t)rowB * a.C + c0);
-                    d = dot_pack(pa, pb); na = dot_pack(pa, pa); nb = dot_pack(pb, pb);
-                }
-                for (int m = 1; m < G; m <<= 1) {
-                    d += __shfl_xor(d, m, 64); na += __shfl_xor(na, m, 64); nb += __shfl_xor(nb, m, 64);
-                }
-                if ((lane & (G - 1)) == 0 && c0 < a.C) acc += d / ((sqrtf(na) + 1e-8f) * (sqrtf(nb) + 1e-8f));
-            }
-            acc = wave_sum(acc);
-            const float sim = acc / (float)a.n_head;
-            if (lane == 0 && sim >= a.temporal_thresh) keep(cd, sim);
-        }
-    } else
-    for (int c = wave; c < total; c += 2 * nwave) {
-        const int c2 = c + nwave;
-        const bool two = c2 < total;
-        const Cand q0 = locate(c), q1 = two ? locate(c2) : q0;
-        const int* lA0 = lists + q0.p * a.rc_stride; const int* lB0 = lA0 + a.rc_stride;
-        const int* lA1 = lists + q1.p * a.rc_stride; const int* lB1 = lA1 + a.rc_stride;
-        const int rowA0 = row_of(lA0, q0.k >> 16, t0 + q0.p), rowB0 = row_of(lB0, q0.k & 0xffff, t0 + q0.p + 1);
-        const int rowA1 = row_of(lA1, q1.k >> 16, t0 + q1.p), rowB1 = row_of(lB1, q1.k & 0xffff, t0 + q1.p + 1);
-        const void* sA0 = src_of(lA0, q0.k >> 16); const void* sB0 = src_of(lB0, q0.k & 0xffff);
-        const void* sA1 = src_of(lA1, q1.k >> 16); const void* sB1 = src_of(lB1, q1.k & 0xffff);
-        // the two lanes that finish the cosines fetch their inverse norms now, under the row loads
-        double pre_ia = 0.0, pre_ib = 0.0;
-        if (lane < 2 && !a.inline_norms) {
-            pre_ia = a.inrm[lane ? rowA1 : rowA0];
-            pre_ib = a.inrm[lane ? rowB1 : rowB0];
-        }
-        float d0 = 0.f, d1 = 0.f, na0 = 0.f, nb0 = 0.f, na1 = 0.f, nb1 = 0.f;
-        for (int c0 = lane * VEC; c0 < a.C; c0 += 64 * VEC) {
-            const Pack<T, VEC> pa0 = load_pack<T, VEC>(sA0, (int64_t)rowA0 * a.C + c0);
-            const Pack<T, VEC> pb0 = load_pack<T, VEC>(sB0, (int64_t)rowB0 * a.C + c0);
-            const Pack<T, VEC> pa1 = load_pack<T, VEC>(sA1, (int64_t)rowA1 * a.C + c0);
-            const Pack<T, VEC> pb1 = load_pack<T, VEC>(sB1, (int64_t)rowB1 * a.C + c0);
-            d0 += dot_pack(pa0, pb0);
-            d1 += dot_pack(pa1, pb1);
-            if (a.inline_norms) {           // the per-head spatial kernel does not produce whole-vector norms
-                na0 += dot_pack(pa0, pa0); nb0 += dot_pack(pb0, pb0);
-                na1 += dot_pack(pa1, pa1); nb1 += dot_pack(pb1, pb1);
-            }
-        }
-        d0 = wave_sum(d0);
-        d1 = wave_sum(d1);
-        if (a.inline_norms) { na0 = wave_sum(na0); nb0 = wave_sum(nb0); na1 = wave_sum(na1); nb1 = wave_sum(nb1); }
-        if (lane < 2 && (lane == 0 || two)) {
-            const float dot = lane ? d1 : d0;
-            // x / (|x| + 1e-8) on both sides (quadtree_temporal_merger.py:62-63); the spatial kernel stored
-            // 1 / (|x| + 1e-8) in double
-            const double ia = a.inline_norms ? 1.0 / (sqrt((double)(lane ? na1 : na0)) + 1e-8) : pre_ia;
-            const double ib = a.inline_norms ? 1.0 / (sqrt((double)(lane ? nb1 : nb0)) + 1e-8) : pre_ib;
-            const float sim = (float)((double)dot * ia * ib);
-            if (sim >= a.temporal_thresh) keep(lane ? q1 : q0, sim);
-        }
-    }
-    // (folded label stage: every wave's edge stores have left before the counts say they are there)
-    if (a.fold_labels) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (a.fold_labels) pair_run<T, VEC, false, true>(pa, geo, r, t0, np, L, smem_raw + sizeof(PairShared));
+    else pair_run<T, VEC, false, false>(pa, geo, r, t0, np, L, smem_raw + sizeof(PairShared));
     STTM_K2_TICK(2);
-    if (wave == 0) {
-        if (lane < np) {
-            const int64_t cidx = (int64_t)r * nf + (t0 + lane);
-            if (a.fold_labels) { st_agent(a.edge_cnt + cidx, nkept[lane]); st_agent(a.cand_cnt + cidx, ncand[lane]); }
-            else { a.edge_cnt[cidx] = nkept[lane]; a.cand_cnt[cidx] = ncand[lane]; }
-            if (ncand[lane] > cap) st_agent(a.bar + 1, 1);     // sticky overflow flag; cannot happen: nested-or-disjoint boxes give < 2A pairs
-        }
-        if (a.fold_labels) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) {
-                const int old = __hip_atomic_fetch_add(a.col_arrive + r, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ps->last = old == nseg - 1 ? 1 : 0;
-            }
-        }
+    if (a.fold_labels && tid == 0) {
+        const int old = __hip_atomic_fetch_add(a.col_arrive + r, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ps->last = old == nseg - 1 ? 1 : 0;
     }
     STTM_K2_TICK(3);
     if (!a.fold_labels) return;
@@ -777,8 +617,7 @@ __global__ void __launch_bounds__(1024) k_pairs(const TemporalArgs a0, const Bat
 }
 
 static size_t pairs_smem(const TemporalArgs& a) {
-    const size_t L = a.pairs_seg;
-    return sizeof(PairShared) + sizeof(int) * (2 * L + (L + 1) * (size_t)a.rc_stride + L * (size_t)a.ecap);
+    return sizeof(PairShared) + pair_lds_bytes(a.pairs_seg, a.rc_stride, a.ecap);
 }
 
 hipError_t launch_pairs(const TemporalArgs& a, const BatchPtrs& bp, int n_videos, hipStream_t stream) {
