@@ -37,24 +37,6 @@ template <typename P> __device__ __forceinline__ void shift_ptr(P*& p, size_t by
     if (p) p = reinterpret_cast<P*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<P>::type*>(p)) + bytes);
 }
 
-// What the pair phase needs, whichever kernel runs it (sttm_pairs.inc)
-struct PairArgs {
-    int T, H, W, C, R;
-    float temporal_thresh;
-    int n_head, head_lanes, inline_norms;
-    const void* S;
-    const void* xrows;
-    const double* inrm;
-    const int* rc_list;
-    int rc_stride;
-    int32_t* edges;
-    float* edge_sim;
-    int32_t* edge_cnt;
-    int32_t* cand_cnt;
-    int ecap;
-    int32_t* bar;             // bar[1]: sticky overflow flag
-};
-
 struct SpatialArgs {
     const void* x;            // [T, H, W, C] memory (channels-last view of the logical [T, C, H, W])
     int64_t sT, sH, sW;       // element strides; the channel stride is 1

@@ -592,15 +592,10 @@ __global__ void __launch_bounds__(1024) k_pairs(const TemporalArgs a0, const Bat
     PairShared* ps = reinterpret_cast<PairShared*>(smem_raw);
     const Column col = make_column(a, g, r);
     const PairGeo geo = {col.Y1, col.X1, col.aw};
-    PairArgs pa;
-    pa.T = a.T; pa.H = a.H; pa.W = a.W; pa.C = a.C; pa.R = a.R;
-    pa.temporal_thresh = a.temporal_thresh; pa.n_head = a.n_head; pa.head_lanes = a.head_lanes; pa.inline_norms = a.inline_norms;
-    pa.S = a.S; pa.xrows = a.xrows; pa.inrm = a.inrm; pa.rc_list = a.rc_list; pa.rc_stride = a.rc_stride;
-    pa.edges = a.edges; pa.edge_sim = a.edge_sim; pa.edge_cnt = a.edge_cnt; pa.cand_cnt = a.cand_cnt; pa.ecap = a.ecap; pa.bar = a.bar;
     const int tid = threadIdx.x;
     if (tid == 0) ps->last = 0;
-    if (a.fold_labels) pair_run<T, VEC, false, true>(pa, geo, r, t0, np, L, smem_raw + sizeof(PairShared));
-    else pair_run<T, VEC, false, false>(pa, geo, r, t0, np, L, smem_raw + sizeof(PairShared));
+    if (a.fold_labels) pair_run<T, VEC, false, true>(a, geo, r, t0, np, L, smem_raw + sizeof(PairShared));
+    else pair_run<T, VEC, false, false>(a, geo, r, t0, np, L, smem_raw + sizeof(PairShared));
     STTM_K2_TICK(2);
     if (a.fold_labels && tid == 0) {
         const int old = __hip_atomic_fetch_add(a.col_arrive + r, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
