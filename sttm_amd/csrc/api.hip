@@ -119,7 +119,7 @@ void root_extent_host(const sttm::LevelDims& g, int I, int J, int* ah, int* aw) 
 struct Buffers {
     char* S; uint32_t* meta; double* inrm; int* rc_list;
     int32_t *edges; float* edge_sim; int32_t *edge_cnt, *cand_cnt; unsigned long long* col_mask; int32_t *col_arrive, *frame_cnt, *bar, *colscratch;
-    int32_t *lab_row, *gcnt;
+    int32_t *lab_row, *gcnt; uint32_t* cgeo;
 };
 
 size_t carve_all(const Plan& p, int T, int H, int W, int C, int dtype, char* base, Buffers* b) {
@@ -143,6 +143,7 @@ size_t carve_all(const Plan& p, int T, int H, int W, int C, int dtype, char* bas
     o.colscratch = c.take<int32_t>(sttm::colscratch_ints(T, H, W, p.R) * 4);
     o.lab_row = c.take<int32_t>(N * 4);
     o.gcnt = c.take<int32_t>(N * 4);
+    o.cgeo = c.take<uint32_t>((size_t)H * W * 4);
     return c.off;
 }
 
@@ -361,7 +362,7 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
     sa.leaves_in_x = dense ? 1 : 0;
     sa.S = b.S; sa.meta = b.meta; sa.inrm = b.inrm; sa.rc_list = b.rc_list;
     sa.rc_stride = p.rc_stride;
-    sa.lab_row = b.lab_row; sa.gcnt = b.gcnt;
+    sa.lab_row = b.lab_row; sa.gcnt = b.gcnt; sa.cgeo = b.cgeo;
     sa.counts = counts;
     sa.frame_cnt = b.frame_cnt;
     sa.bar = b.bar;
@@ -390,7 +391,7 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
     ta.ecap_magic = 0xffffffffu / (unsigned)p.ecap + 1u;
     ta.col_mask = b.col_mask; ta.col_arrive = b.col_arrive; ta.frame_cnt = b.frame_cnt; ta.bar = b.bar;
     ta.colscratch = b.colscratch;
-    ta.gm_split = gm_split_for(T); ta.lab_row = b.lab_row; ta.gcnt = b.gcnt;
+    ta.gm_split = gm_split_for(T); ta.lab_row = b.lab_row; ta.gcnt = b.gcnt; ta.cgeo = b.cgeo;
     ta.counts = counts;
     ta.counts_host = counts_host; ta.seq = seq;
     ta.feat_out = feat_out[0]; ta.npatch_out = npatch_out[0]; ta.tlbr_out = tlbr_out[0];
@@ -567,7 +568,7 @@ int sttm_quadtree_apply(const void* v, int64_t stride_t, int64_t stride_c, int64
     ta.dtype = dtype_v; ta.vec = vec;
     ta.weighted_avg = sum_mode ? 1 : 0;
     ta.S = b.S; ta.xrows = dense ? v : nullptr;
-    ta.frame_cnt = b.frame_cnt; ta.lab_row = b.lab_row; ta.gcnt = b.gcnt;
+    ta.frame_cnt = b.frame_cnt; ta.lab_row = b.lab_row; ta.gcnt = b.gcnt; ta.cgeo = b.cgeo;
     ta.meta = b.meta; ta.gm_split = gm_split_for(T);
     ta.counts = const_cast<int32_t*>(counts);
     ta.feat_out = out;
@@ -602,7 +603,8 @@ int sttm_wait_counts(const int32_t* counts_host, int seq, int timeout_us) {
 // development build only (not in the public header): measurement hooks of tools/*_ticks.py and tools/k1_ablate.py.
 // ticks: device buffer of >= 48 long longs -- [0, 16) spatial workgroup k1_wg, [16, 32) pair workgroup k2_wg, [32, 48) label
 // stage of column lbl_col -- or NULL to switch the stamps off.
-int sttm_dev_k1_span(long long* span) { g_dev.k1_span = span; return STTM_OK; }   // [2 * T * R] device buffer or NULL
+int sttm_dev_k1_span(long long* span) { g_dev.k1_span = span; return STTM_OK; }
+int sttm_dev_k5_mode(int mode) { g_dev.k5_mode = mode; return STTM_OK; }   // [2 * T * R] device buffer or NULL
 int sttm_dev_hooks(int k1_mode, long long* ticks, int k1_wg, int k2_wg, int lbl_col) {
     g_dev.k1_mode = k1_mode;
     g_dev.k1_ticks = ticks; g_dev.k1_wg = k1_wg;

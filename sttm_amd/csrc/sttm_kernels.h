@@ -17,6 +17,7 @@ struct DevHooks {
     long long* lbl_ticks;     // stamps of the label stage of column lbl_col
     int lbl_col;
     long long* k1_span;       // [2 * workgroups] start / end stamp of EVERY spatial workgroup (null = off)
+    int k5_mode;              // group-mean ablation: 1 = no member scan (every survivor treated as a singleton; outputs invalid)
 };
 #define STTM_DEV_TICK(hooks, field, sel, n) \
     do { if ((hooks).field && (sel) && threadIdx.x == 0) (hooks).field[n] = wall_clock64(); } while (0)
@@ -56,6 +57,7 @@ struct SpatialArgs {
     int rc_stride;
     int32_t* lab_row;         // [T*H*W] default labels: a node's own origin row, -1 where no node starts
     int32_t* gcnt;            // [T*H*W] default group sizes: 1 at a node's origin row, else 0
+    uint32_t* cgeo;           // [H*W] per leaf position: its root cell's first leaf row / column and extent, Y1 | X1<<8 | aw<<16 | ah<<24
     int32_t* counts;          // STTM_CNT_* slots (zeroed here, filled by the later kernels)
     int32_t* frame_cnt;       // [T] zeroed here for the label stage
     int32_t* bar;             // [4] zeroed here: [0] grid-barrier counter of the label stage, [2..3] the 64-bit arrival/total word
@@ -69,7 +71,7 @@ __device__ __forceinline__ void rebase(SpatialArgs& a, const BatchPtrs& bp, int 
     if (v == 0) return;
     const size_t off = (size_t)v * bp.ws_stride;
     shift_ptr(a.S, off); shift_ptr(a.meta, off); shift_ptr(a.inrm, off); shift_ptr(a.rc_list, off); shift_ptr(a.lab_row, off);
-    shift_ptr(a.gcnt, off); shift_ptr(a.frame_cnt, off); shift_ptr(a.bar, off); shift_ptr(a.col_arrive, off);
+    shift_ptr(a.gcnt, off); shift_ptr(a.frame_cnt, off); shift_ptr(a.bar, off); shift_ptr(a.col_arrive, off); shift_ptr(a.cgeo, off);
     a.counts += (size_t)v * STTM_CNT_SLOTS;
 }
 hipError_t launch_spatial(const SpatialArgs& a, const BatchPtrs& bp, int n_videos, int dtype, int vec, int nt, hipStream_t stream);
@@ -115,6 +117,7 @@ struct TemporalArgs {
     int gm_split;             // group-mean workgroups per frame
     int32_t* lab_row;         // [T*H*W] by origin row: origin row of the node's representative (-1: no node starts here)
     int32_t* gcnt;            // [T*H*W] by origin row: members of the group this node represents; 0 = not a survivor
+    const uint32_t* cgeo;     // [H*W] root-cell geometry of every leaf position (written by the spatial kernel)
     int32_t* counts;
     int32_t* counts_host;     // optional host-mapped (pinned) mirror of counts, published by the label stage with slot 7 = seq
     int seq;
@@ -134,7 +137,7 @@ __device__ __forceinline__ void rebase(TemporalArgs& a, const BatchPtrs& bp, int
     shift_ptr(a.S, off); shift_ptr(a.meta, off); shift_ptr(a.inrm, off); shift_ptr(a.rc_list, off);
     shift_ptr(a.edges, off); shift_ptr(a.edge_sim, off); shift_ptr(a.edge_cnt, off); shift_ptr(a.cand_cnt, off);
     shift_ptr(a.col_mask, off); shift_ptr(a.col_arrive, off); shift_ptr(a.frame_cnt, off); shift_ptr(a.bar, off);
-    shift_ptr(a.colscratch, off); shift_ptr(a.lab_row, off); shift_ptr(a.gcnt, off);
+    shift_ptr(a.colscratch, off); shift_ptr(a.lab_row, off); shift_ptr(a.gcnt, off); shift_ptr(a.cgeo, off);
     a.counts += (size_t)v * STTM_CNT_SLOTS;
     if (a.counts_host) a.counts_host += (size_t)v * STTM_CNT_SLOTS;
     a.seq += v;

@@ -71,6 +71,17 @@ __device__ __forceinline__ Column make_column(const TemporalArgs& a, const Level
     c.fast = (unsigned long long)c.slots * (unsigned long long)c.A <= (1ull << 32);
     return c;
 }
+// the same from the packed geometry word the spatial kernel left for every leaf position (no level-table walk)
+__device__ __forceinline__ Column column_from_geo(const TemporalArgs& a, uint32_t gw) {
+    Column c;
+    c.Y1 = gw & 255; c.X1 = (gw >> 8) & 255; c.aw = (gw >> 16) & 255; c.ah = gw >> 24;
+    c.A = c.ah * c.aw; c.slots = a.T * c.A;
+    c.base = a.T * (c.Y1 * a.W + c.ah * c.X1);
+    c.mA = 0xffffffffu / (unsigned)c.A + 1u;
+    c.maw = 0xffffffffu / (unsigned)c.aw + 1u;
+    c.fast = (unsigned long long)c.slots * (unsigned long long)c.A <= (1ull << 32);
+    return c;
+}
 // root cell of leaf (y, x): walk the parents up from the leaf level
 __device__ __forceinline__ int root_cell_of(const LevelDims& g, int y, int x) {
     int i = y, j = x;
@@ -900,7 +911,6 @@ template <> __device__ __forceinline__ float round_to<f16_t>(float f) { return f
 
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256, TypeInfo<T>::lowp ? 6 : 8) k_group_mean(const TemporalArgs a0, const BatchPtrs bp) {
-    const LevelDims& g = a0.dims;          // see k_col_labels
     TemporalArgs a = a0;
     rebase(a, bp, blockIdx.y);
     // Workgroup (t, s): `gm_split` workgroups share frame t.  Every wave scans the frame's H*W origin slots (one ballot
@@ -941,7 +951,10 @@ __global__ void __launch_bounds__(256, TypeInfo<T>::lowp ? 6 : 8) k_group_mean(c
                 sel &= sel - 1ull;
                 const int p = base + b * 64 + l;
                 const int row = row0 + j0 + __popcll(m & ((1ull << l) - 1ull));
-                const int n = __builtin_amdgcn_readlane(cnt[b], l);
+                int n = __builtin_amdgcn_readlane(cnt[b], l);
+#ifdef STTM_DEV
+                if (a.dev.k5_mode == 1) n = 1;
+#endif
                 const uint32_t mt = (uint32_t)__builtin_amdgcn_readlane((int)meta[b], l);
                 const int origin = t * HW + p;
                 const int y1 = p / a.W, x1 = p - y1 * a.W;
@@ -952,7 +965,7 @@ __global__ void __launch_bounds__(256, TypeInfo<T>::lowp ? 6 : 8) k_group_mean(c
                 Column col;
                 int slot0 = 0;
                 if (n > 1) {
-                    col = make_column(a, g, root_cell_of(g, y1, x1));
+                    col = column_from_geo(a, a.cgeo[p]);              // one wave-uniform load instead of a walk over the level table
                     slot0 = t * col.A + (y1 - col.Y1) * col.aw + (x1 - col.X1);
                 }
                 int patches = own_area;

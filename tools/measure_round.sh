@@ -10,10 +10,10 @@ for V in "$@"; do
     N=$(echo "$V" | tr ' =' '__')
     env $V $B --no-extensions > gpurun_out/${TAG}_bench_$N.json 2> gpurun_out/${TAG}_bench_$N.err
 done
-bash tools/profile_bench.sh $TAG --steps 1 --warmup 1 --videos-per-step 512 --profile-calls 8
+bash tools/profile_bench.sh ${TAG}_prof --steps 1 --warmup 1 --videos-per-step 512 --profile-calls 8
 python - <<PY
 import json, glob
-for f in sorted(glob.glob("gpurun_out/${TAG}_bench*.json")):
+for f in sorted(glob.glob("gpurun_out/${TAG}_bench*.json")) :
     try:
         d = json.loads(open(f).read().strip().splitlines()[-1])
     except Exception as e:
@@ -22,4 +22,4 @@ for f in sorted(glob.glob("gpurun_out/${TAG}_bench*.json")):
     print(f.split("/")[-1], "value", d["value"], "device_ms", r["device_ms_per_video"], "frac", r["frac"], r["kernel_ms"],
           {k: d[k]["value"] for k in ("batched_extension", "threaded_dropin_extension", "tome_extension") if k in d})
 PY
-cat gpurun_out/${TAG}_kernels.md
+cat gpurun_out/${TAG}_prof_kernels.md
