@@ -69,3 +69,51 @@ def resize_nearest(tokens, height, width, size):
                                      torch.cuda.current_stream(x.device).cuda_stream)
     _lib.raise_for(rc)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# On-disk feature formats of the reference's pre-extraction scripts (second half)
+# ---------------------------------------------------------------------------------------------------
+def _load_pt(path):
+    feat = torch.load(path, map_location="cpu", weights_only=True)
+    if not torch.is_tensor(feat):
+        raise ValueError(f"{path}: expected one tensor (torch.save(video_feats.cpu(), ...)), got {type(feat).__name__}")
+    return feat
+
+
+def load_llavavideo_features(path, device, projector=None, stride=2, mode="bilinear", dtype=torch.bfloat16):
+    """`<vid>.pt` written by llava/eval/video_feat_llavavideo.py:89-95: ONE tensor [T, 729, 1152] bfloat16 -- the SigLIP tower's
+    27 x 27 patch tokens per frame, BEFORE the multimodal projector.  The reference's evaluation moves it to the GPU
+    (eval_vidqa_by_feat_llavavideo.py:213), projects it (llava_arch.py:238, `mm_projector`: model weights, the caller's) and pools
+    27 x 27 -> 14 x 14 (`get_2dPool`, llava_arch.py:173-198).  This does the same with the HIP pooling kernel and returns the
+    video in the layout the merge path takes: a logical [T, C, 14, 14] view of [T, 14, 14, C] memory (zero-copy for
+    get_quadtree_features / get_tome_features), plus the pooled side.
+    projector: callable [T, 729, Cv] -> [T, 729, C] on the device, or None when the file already holds projected tokens."""
+    feat = _load_pt(path)
+    if feat.dim() != 3:
+        raise ValueError(f"{path}: expected [T, tokens, C], got {tuple(feat.shape)}")
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("sttm_amd runs on the GPU only: load onto a CUDA (ROCm) device; there is no CPU fallback")
+    x = feat.to(dtype).to(dev, non_blocking=True)
+    if projector is not None:
+        x = projector(x)
+    T, n_tok, C = x.shape
+    pooled = get_2dPool(x, stride=stride, mode=mode)                     # [T, side*side, C]
+    side = int(round(math.sqrt(pooled.shape[1])))
+    return pooled.reshape(T, side, side, C).permute(0, 3, 1, 2), side
+
+
+def load_qwen2vl_features(path, device, dtype=torch.bfloat16):
+    """`<vid>.pt` written by llava/eval/video_feat_qwen2vl.py:72-79: ONE tensor [T, H, W, C] (the merged-patch grid of the Qwen2-VL
+    vision tower, variable H x W per video).  The evaluation casts to bfloat16 on the GPU (eval_vidqa_by_feat_qwen2vl.py:152) and
+    flattens to (T H W) C; the hook later views the slice as [T, C, H, W].  Returns that view (zero-copy) and (T, H, W)."""
+    feat = _load_pt(path)
+    if feat.dim() != 4:
+        raise ValueError(f"{path}: expected [T, H, W, C], got {tuple(feat.shape)}")
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("sttm_amd runs on the GPU only: load onto a CUDA (ROCm) device; there is no CPU fallback")
+    x = feat.to(dtype).to(dev, non_blocking=True).contiguous()
+    T, H, W, _ = x.shape
+    return x.permute(0, 3, 1, 2), (T, H, W)

@@ -136,3 +136,14 @@ def test_product_library_has_no_measurement_hooks():
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sttm_amd", "csrc", "api.hip")).read()
     body = src[src.index("int merge_group("):src.index("}  // namespace\n\nextern")]
     assert "getenv" not in body          # tuning switches are read once (config()), never per call
+
+
+def test_feature_file_loaders_refuse_the_cpu(tmp_path):
+    import torch
+    from sttm_amd.upstream import load_llavavideo_features, load_qwen2vl_features
+    p = tmp_path / "v.pt"
+    torch.save(torch.zeros(2, 729, 8, dtype=torch.bfloat16), p)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        load_llavavideo_features(str(p), "cpu")
+    with pytest.raises(ValueError):
+        load_qwen2vl_features(str(p), "cuda:0")              # a [T, tokens, C] file is not the Qwen2-VL [T, H, W, C] format

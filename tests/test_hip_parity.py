@@ -110,6 +110,7 @@ ORACLE_CASES = [
     (128, 1024, 13, 24, 32, torch.float32, 0.85, 0.60, 1, False),  # C4: Qwen2-VL grid, full length (run_vidqa.sh:84)
     (180, 1024, 14, 14, 33, torch.float32, 0.94, 0.82, 1, False),  # C5: MLVU 180 frames (run_vidqa.sh:89)
     (180, 1024, 14, 14, 34, torch.bfloat16, 0.94, 0.82, 1, False),
+    (4200, 16, 14, 14, 35, torch.float32, 0.85, 0.55, 1, False),   # 67 200 label slots per column: past the 16-bit slot ids of round 1
 ]
 
 

@@ -113,3 +113,41 @@ def test_pyrd_pattern_runs_on_device():
         assert out.shape == ref.shape and torch.allclose(out, ref, atol=2e-5)
     finally:
         MPI.restore_qwen2()
+
+
+def test_feature_files_of_the_reference_feed_the_merge_path(tmp_path):
+    """The on-disk formats of the reference's extraction scripts (video_feat_llavavideo.py:89-95: [T, 729, 1152] bf16 before the
+    projector; video_feat_qwen2vl.py:72-79: [T, H, W, C]) -> loader -> projector (caller's) -> HIP 27->14 pooling -> the merge
+    path, against the same steps in plain torch + the oracle."""
+    import torch.nn.functional as F
+    from oracle import sttm_oracle as O
+    from sttm_amd import get_quadtree_features
+    from sttm_amd.upstream import load_llavavideo_features, load_qwen2vl_features
+    g = torch.Generator().manual_seed(3)
+    T, Cv, C = 6, 96, 128
+    tower = (torch.randn(T, 1, Cv, generator=g) * 0.5 + torch.randn(1, 729, Cv, generator=g) + 0.3 * torch.randn(T, 729, Cv, generator=g)).bfloat16()
+    path = tmp_path / "vid0.pt"
+    torch.save(tower, path)
+    proj = torch.nn.Linear(Cv, C).to(DEV, torch.bfloat16)
+    with torch.no_grad():
+        video, side = load_llavavideo_features(str(path), DEV, projector=proj)
+        assert side == 14 and video.shape == (T, C, 14, 14) and video.dtype == torch.bfloat16 and video.stride(1) == 1
+        # the reference's steps in torch: project, NCHW bilinear resize to ceil(27 / 2) = 14, back to tokens
+        ref = proj(tower.to(DEV)).view(T, 27, 27, C).permute(0, 3, 1, 2)
+        ref = F.interpolate(ref.float(), size=(14, 14), mode="bilinear").to(torch.bfloat16)
+        d = (video.float() - ref.float()).abs() / ref.float().abs().clamp_min(1.0)
+        assert float(d.max()) <= 2 ** -7                                    # one bf16 ulp (the fp32 taps are rounded once either way)
+        out = get_quadtree_features(video, 0.85, 0.55, 1)
+        exp = O.get_quadtree_features(video.cpu(), 0.85, 0.55, 1)
+        assert torch.equal(out[2].cpu(), exp[2]) and torch.equal(out[1].cpu(), exp[1])
+    grid = torch.randn(5, 10, 18, 64, generator=g).bfloat16()
+    path2 = tmp_path / "vid1.pt"
+    torch.save(grid, path2)
+    v2, (t2, h2, w2) = load_qwen2vl_features(str(path2), DEV)
+    assert (t2, h2, w2) == (5, 10, 18) and v2.shape == (5, 64, 10, 18) and v2.stride(1) == 1
+    assert torch.equal(v2.permute(0, 2, 3, 1).cpu().view(torch.int16), grid.view(torch.int16))
+    out = get_quadtree_features(v2, 0.85, 0.6, 1)
+    exp = O.get_quadtree_features(v2.cpu(), 0.85, 0.6, 1)
+    assert torch.equal(out[2].cpu(), exp[2])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        load_qwen2vl_features(str(path2), "cpu")
