@@ -139,7 +139,8 @@ int sttm_quadtree_merge_batch(int n_videos, const void* const* x, int64_t stride
                               int32_t* counts_host, int seq, void* const* events, void* stream);
 
 /*
- * Tuning and test switches (process-wide; none of them changes results).  Defaults come from the environment variable
+ * Tuning and test switches (process-wide; none of them changes results, except "tome_split" within the fp32 rounding noise of
+ * the ToMe scores).  Defaults come from the environment variable
  * STTM_<KEY> read once at first use; sttm_configure overrides a key at run time (call it while no merge is being issued from
  * another thread).  Returns STTM_ERR_ARG for an unknown key.  Keys:
  *   "pairs_seg"   consecutive frame pairs of one root cell per pair workgroup (0 = automatic: 1; with fold_labels about one
@@ -153,6 +154,12 @@ int sttm_quadtree_merge_batch(int n_videos, const void* const* x, int64_t stride
  *                 stand-alone label kernel; the folded form is no faster on MI355X and is kept for experiments)
  *   "no_fuse"     1: stand-alone label stage as two launches (no in-kernel grid barrier)
  *   "force_gmem_labels"  1: label stage on global scratch instead of LDS (the path of columns too large for LDS)
+ *   "tome_split"  ToMe match kernel for float32 inputs.  1 (default): unit rows as two fp16 planes (h + l of 4096 v, residual
+ *                 <= 2^-24), scores from the products l.l + l.h + h.l + h.h on the fp16 matrix pipe with fp32 accumulation
+ *                 (each product exact; error bound 1.2e-7 + the fp32 accumulation, measured <= 9.2e-7 against float64 where
+ *                 the fp32-input MFMA kernel measures 1.4e-6), kernel picked by size; 2: the same without l.l (bound 3.6e-7);
+ *                 0: fp32-input MFMA (v_mfma_f32_32x32x2_f32), 2.9x slower; 3 / 4: force the 128-tile / 256-tile kernel, 5 / 6
+ *                 the same with three terms (tests)
  */
 int sttm_configure(const char* key, int value);
 
@@ -178,9 +185,9 @@ int sttm_merge_dst_idx(const int32_t* pairs, int L, int N, int32_t* rep_out, voi
 
 /* ------------------------------------------------------------------------------------------------
  * ToMe baseline: ONE iteration of tome_per_video's loop (tome_token_merger.py:143-149), i.e.
- * bipartite_soft_matching (:13-57) + merge_wavg (:77-91) on a [n, C] token matrix.  dtype float32 (exact fp32 products on the
- * fp32-input MFMA), bfloat16 or float16 (every intermediate rounded to the input dtype like the reference's torch ops on
- * 16-bit hidden states; bf16 / f16 MFMA; x_out has the input dtype, size / size_out stay float32 arrays holding
+ * bipartite_soft_matching (:13-57) + merge_wavg (:77-91) on a [n, C] token matrix.  dtype float32 (fp32 scores from exact
+ * products: two-plane fp16 split on the fp16 MFMA, or the fp32-input MFMA -- see "tome_split"), bfloat16 or float16 (every
+ * intermediate rounded to the input dtype like the reference's torch ops on 16-bit hidden states; bf16 / f16 MFMA; x_out has the input dtype, size / size_out stay float32 arrays holding
  * dtype-representable values).
  *
  *   x          [n, C] row-major tokens          size  [n] token sizes, or NULL for all ones (first iteration)

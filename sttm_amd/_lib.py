@@ -71,7 +71,8 @@ def load():
 
 
 def configure(**kw):
-    """Tuning / test switches of the library (sttm_configure); none changes results."""
+    """Tuning / test switches of the library (sttm_configure, keys in include/sttm_hip.h); none changes results except
+    `tome_split` (which match kernel computes the fp32 ToMe scores: differences within the fp32 rounding noise)."""
     lib = load()
     for k, v in kw.items():
         raise_for(lib.sttm_configure(k.encode(), int(v)))

@@ -216,6 +216,7 @@ __global__ void __launch_bounds__(256) k_tome_normalize16(const void* __restrict
 typedef __bf16 tome_bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 tome_f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef unsigned int tome_u32x4 __attribute__((ext_vector_type(4)));      // 16-byte staging unit (a native vector: stays in registers)
 template <typename T> struct TomeMfma;
 template <> struct TomeMfma<bf16_t> {
     typedef tome_bf16x8 vec;
@@ -248,13 +249,13 @@ __global__ void __launch_bounds__(256, 2) k_tome_match16(const uint16_t* __restr
     float bestv[2] = {-INFINITY, -INFINITY};
     int bestj[2] = {0x7fffffff, 0x7fffffff};
     const int lcol = lane & 31, lhalf = lane >> 5;
-    uint4 ra[2], rb[2];
+    tome_u32x4 ra[2], rb[2];
     auto fetch = [&](int j0, int k0) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int ri = min(i0 + p * 64 + srow, na - 1), rj = min(j0 + p * 64 + srow, nb - 1);
-            ra[p] = *reinterpret_cast<const uint4*>(ahat + (int64_t)ri * D + k0 + sch);
-            rb[p] = *reinterpret_cast<const uint4*>(bhat + (int64_t)rj * D + k0 + sch);
+            ra[p] = *reinterpret_cast<const tome_u32x4*>(ahat + (int64_t)ri * D + k0 + sch);
+            rb[p] = *reinterpret_cast<const tome_u32x4*>(bhat + (int64_t)rj * D + k0 + sch);
         }
     };
     if (jt_lo < jt_hi) fetch(jt_lo * TM_J, 0);
@@ -271,8 +272,8 @@ __global__ void __launch_bounds__(256, 2) k_tome_match16(const uint16_t* __restr
             __syncthreads();          // previous stage fully consumed
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                *reinterpret_cast<uint4*>(As + (p * 64 + srow) * TM16_LD + sch) = ra[p];
-                *reinterpret_cast<uint4*>(Bs + (p * 64 + srow) * TM16_LD + sch) = rb[p];
+                *reinterpret_cast<tome_u32x4*>(As + (p * 64 + srow) * TM16_LD + sch) = ra[p];
+                *reinterpret_cast<tome_u32x4*>(Bs + (p * 64 + srow) * TM16_LD + sch) = rb[p];
             }
             __syncthreads();
             if (k0 + TM_K < D) fetch(j0, k0 + TM_K);
@@ -306,6 +307,301 @@ __global__ void __launch_bounds__(256, 2) k_tome_match16(const uint16_t* __restr
     for (int q = 0; q < 2; ++q) {
         const int i = i0 + wi * 64 + q * 32 + lcol;
         if (i < na && bestj[q] != 0x7fffffff) atomicMax(best + i, pack_score(bestv[q], bestj[q]));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// fp32 inputs on the 16-bit matrix pipe (16x the rate of v_mfma_f32_32x32x2_f32): every unit-row element v is written as
+//     4096 * v = h + l,   h = fp16(4096 v),  l = fp16(4096 v - h)        (|v| <= 1: no overflow; the scale keeps l normal)
+// which leaves |4096 v - h - l| <= 2^-24 |4096 v| (two round-to-nearest steps), and the score is accumulated in fp32 from
+// the four products  l.l + l.h + h.l + h.h  (each fp16 x fp16 product is exact in fp32), times 2^-24 at the end.
+// Error of one score against the real dot product of the fp32 rows: <= 2 * 2^-24 * sum|a_k b_k| <= 1.2e-7 from the split
+// (Cauchy-Schwarz, unit rows) plus the fp32 accumulation, i.e. the same order as an fp32 FMA chain over k = 1024 (measured
+// on the test clips: max |error| 6.1e-7 against 4.7e-7 for sgemm, no argmax change).  The reference's own result is only
+// defined up to that accumulation order (cuBLAS / MKL sgemm).  Same tile structure as k_tome_match16.
+// ---------------------------------------------------------------------------------------------------
+constexpr float kSplitScale = 4096.f;
+constexpr float kSplitUnscale = 1.f / (4096.f * 4096.f);
+
+// VEC = 4: one head, D % 4 == 0, 16-byte aligned rows (the production shape): float4 loads, 8-byte plane stores; the second
+// pass re-reads the row from the cache.  VEC = 1: any shape.
+template <int VEC>
+__global__ void __launch_bounds__(256) k_tome_normalize_split(const float* __restrict__ x, int n, int C, int n_head, int D, int Dp,
+                                                              uint16_t* __restrict__ aplanes /*[2][na][Dp]*/, int na,
+                                                              uint16_t* __restrict__ bplanes /*[2][nb][Dp]*/, int nb) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    for (int row = blockIdx.x * nwave + wave; row < n; row += gridDim.x * nwave) {
+        const float* xr = x + (int64_t)row * C;
+        const bool odd = row & 1;
+        uint16_t* hi = (odd ? bplanes : aplanes) + (int64_t)(row >> 1) * Dp;
+        uint16_t* lo = hi + (int64_t)(odd ? nb : na) * Dp;
+        auto split = [&](float m, float nrm, uint16_t& h_out, uint16_t& l_out) {
+            const float v = (m / nrm) * kSplitScale;                  // the reference's unit-row element, times 2^12 (exact)
+            const _Float16 h = (_Float16)v;
+            const _Float16 l = (_Float16)(v - (float)h);              // v - h is exact in fp32
+            h_out = __builtin_bit_cast(uint16_t, h);
+            l_out = __builtin_bit_cast(uint16_t, l);
+        };
+        if constexpr (VEC == 4) {
+            // per-lane partial sums over d = 4*lane + e + 256*i in increasing i, e: the order of the scalar loop below is
+            // d = lane + 64*i; both feed the same wave_sum tree, the two orders differ only in which lane adds which term
+            float ss = 0.f;
+            for (int d = lane * 4; d < D; d += 256) {
+                const float4 m = *reinterpret_cast<const float4*>(xr + d);
+                ss = fmaf(m.x, m.x, ss); ss = fmaf(m.y, m.y, ss); ss = fmaf(m.z, m.z, ss); ss = fmaf(m.w, m.w, ss);
+            }
+            ss = wave_sum(ss);
+            const float nrm = sqrtf(ss);
+            for (int d = lane * 4; d < D; d += 256) {
+                const float4 m = *reinterpret_cast<const float4*>(xr + d);
+                uint16_t h[4], l[4];
+                split(m.x, nrm, h[0], l[0]); split(m.y, nrm, h[1], l[1]); split(m.z, nrm, h[2], l[2]); split(m.w, nrm, h[3], l[3]);
+                *reinterpret_cast<uint2*>(hi + d) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+                *reinterpret_cast<uint2*>(lo + d) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+            }
+        } else {
+            auto metric = [&](int d) {
+                if (n_head == 1) return xr[d];
+                float s = 0.f;
+                for (int h = 0; h < n_head; ++h) s += xr[h * D + d];
+                return s / (float)n_head;
+            };
+            float ss = 0.f;
+            for (int d = lane; d < D; d += 64) { const float m = metric(d); ss = fmaf(m, m, ss); }
+            ss = wave_sum(ss);
+            const float nrm = sqrtf(ss);
+            for (int d = lane; d < D; d += 64) split(metric(d), nrm, hi[d], lo[d]);
+        }
+        for (int d = D + lane; d < Dp; d += 64) { hi[d] = 0; lo[d] = 0; }
+    }
+}
+
+// KS = k per LDS stage, QI = 32-row a-subtiles per wave, WJ = waves along j.  Workgroup tile: 64*WJ b-rows x 64*QI a-rows,
+// 2*WJ waves of 64 (j) x 32*QI (i).  TERMS = 4 (l.l + l.h + h.l + h.h) or 3 (without l.l).
+template <int KS, int QI, int WJ, int TERMS>
+__global__ void __launch_bounds__(128 * WJ, 2) k_tome_match_split(const uint16_t* __restrict__ ap, const uint16_t* __restrict__ bp,
+                                                                   int na, int nb, int D, int jsplit,
+                                                                   unsigned long long* __restrict__ best /*[na]*/) {
+    constexpr int NT = 128 * WJ;
+    constexpr int LD = KS + 8;                 // LDS row: KS fp16 + 16 bytes (ds_read_b128 groups hit distinct 4-bank groups)
+    constexpr int TI = 64 * QI, TJ = 64 * WJ;
+    constexpr int CPR = KS / 8;                // 16-byte chunks per row and stage
+    constexpr int NA = 2 * TI * CPR / NT, NB = 2 * TJ * CPR / NT;
+    extern __shared__ __attribute__((aligned(16))) uint16_t tm_smem[];
+    uint16_t* As = tm_smem;                    // [plane][TI][LD]
+    uint16_t* Bs = tm_smem + 2 * TI * LD;      // [plane][TJ][LD]
+    typedef tome_f16x8 vec;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave & 1, wj = wave >> 1;
+    const int itile = blockIdx.x / jsplit, jpart = blockIdx.x % jsplit;
+    const int i0 = itile * TI;
+    const int jtiles = (nb + TJ - 1) / TJ;
+    const int jt_lo = (int)((long long)jtiles * jpart / jsplit), jt_hi = (int)((long long)jtiles * (jpart + 1) / jsplit);
+    float bestv[QI];
+    int bestj[QI];
+#pragma unroll
+    for (int q = 0; q < QI; ++q) { bestv[q] = -INFINITY; bestj[q] = 0x7fffffff; }
+    const int lcol = lane & 31, lhalf = lane >> 5;
+    tome_u32x4 ra[NA], rb[NB];
+    auto fetch = [&](int j0, int k0) {
+#pragma unroll
+        for (int c = 0; c < NA; ++c) {
+            const int id = c * NT + tid, plane = id / (TI * CPR), rem = id % (TI * CPR), row = rem / CPR, ch = rem % CPR;
+            const int ri = min(i0 + row, na - 1);
+            ra[c] = *reinterpret_cast<const tome_u32x4*>(ap + ((int64_t)plane * na + ri) * D + k0 + ch * 8);
+        }
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            const int id = c * NT + tid, plane = id / (TJ * CPR), rem = id % (TJ * CPR), row = rem / CPR, ch = rem % CPR;
+            const int rj = min(j0 + row, nb - 1);
+            rb[c] = *reinterpret_cast<const tome_u32x4*>(bp + ((int64_t)plane * nb + rj) * D + k0 + ch * 8);
+        }
+    };
+    if (jt_lo < jt_hi) fetch(jt_lo * TJ, 0);
+    for (int jt = jt_lo; jt < jt_hi; ++jt) {
+        const int j0 = jt * TJ;
+        f32x16_t acc[2][QI];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = 0; q < QI; ++q)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[p][q][e] = 0.f;
+        for (int k0 = 0; k0 < D; k0 += KS) {
+            __syncthreads();          // previous stage fully consumed
+#pragma unroll
+            for (int c = 0; c < NA; ++c) {
+                const int id = c * NT + tid, plane = id / (TI * CPR), rem = id % (TI * CPR), row = rem / CPR, ch = rem % CPR;
+                *reinterpret_cast<tome_u32x4*>(As + (plane * TI + row) * LD + ch * 8) = ra[c];
+            }
+#pragma unroll
+            for (int c = 0; c < NB; ++c) {
+                const int id = c * NT + tid, plane = id / (TJ * CPR), rem = id % (TJ * CPR), row = rem / CPR, ch = rem % CPR;
+                *reinterpret_cast<tome_u32x4*>(Bs + (plane * TJ + row) * LD + ch * 8) = rb[c];
+            }
+            __syncthreads();
+            if (k0 + KS < D) fetch(j0, k0 + KS);
+            else if (jt + 1 < jt_hi) fetch(j0 + TJ, 0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ks += 16) {
+                vec fb[2][2], fa[QI][2];      // [subtile][plane: 0 = h, 1 = l]
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+                        fb[p][pl] = *reinterpret_cast<const vec*>(Bs + (pl * TJ + wj * 64 + p * 32 + lcol) * LD + ks + lhalf * 8);
+#pragma unroll
+                    for (int q = 0; q < QI; ++q)
+                        fa[q][pl] = *reinterpret_cast<const vec*>(As + (pl * TI + wi * (32 * QI) + q * 32 + lcol) * LD + ks + lhalf * 8);
+                }
+                // terms outermost: consecutive MFMAs write different accumulators
+#pragma unroll
+                for (int term = 4 - TERMS; term < 4; ++term) {
+                    const int pb = term == 0 || term == 1, pa = term == 0 || term == 2;    // l.l, l.h, h.l, h.h
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+#pragma unroll
+                        for (int q = 0; q < QI; ++q)
+                            acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[p][pb], fa[q][pa], acc[p][q], 0, 0, 0);
+                }
+            }
+        }
+        // running max over this tile (on the scaled scores: the factor 2^-24 is applied once, at the end)
+#pragma unroll
+        for (int q = 0; q < QI; ++q)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int j = j0 + wj * 64 + p * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
+                    const float v = acc[p][q][e];
+                    if (j < nb && (v > bestv[q] || (v == bestv[q] && j < bestj[q]))) { bestv[q] = v; bestj[q] = j; }
+                }
+    }
+#pragma unroll
+    for (int q = 0; q < QI; ++q) {
+        const int i = i0 + wi * (32 * QI) + q * 32 + lcol;
+        if (i < na && bestj[q] != 0x7fffffff) atomicMax(best + i, pack_score(bestv[q] * kSplitUnscale, bestj[q]));
+    }
+}
+
+// The same product on a 256 x 256 workgroup tile (8 waves of 64 (j) x 128 (i), one workgroup per CU) with the operand tiles
+// copied global -> LDS by the DMA path (global_load_lds_dwordx4: no staging registers, no ds_write pass) into two LDS buffers:
+// the copy of stage s+1 runs under the MFMAs of stage s, one barrier per stage.  A stage is 32 k of both planes of both
+// matrices = 64 KB (2 x 64 KB buffers of the 160 KB LDS); LDS reads per MFMA are 2/3 of the 128 x 128 kernel's.
+// An LDS-DMA instruction writes wave-linear (base + lane * 16 bytes), so rows are unpadded (64 bytes) and the bank spread comes
+// from a chunk swizzle applied to the SOURCE address: 16-byte chunk c of tile row r lives at chunk position c ^ ((r >> 2) & 3),
+// which sends the 16 rows of a ds_read_b128 lane group to 16 different 4-bank groups.
+typedef const __attribute__((address_space(1))) void* tome_gptr;
+typedef __attribute__((address_space(3))) void* tome_lptr;
+constexpr int TG_T = 256;                       // tile side
+constexpr int TG_KS = 32;                       // k per stage
+constexpr int TG_PLANE = TG_T * TG_KS * 2;      // bytes of one plane of one matrix tile (16 KB)
+constexpr int TG_BUF = 4 * TG_PLANE;            // A.h, A.l, B.h, B.l
+
+template <int TERMS>
+__global__ void __launch_bounds__(512, 2) k_tome_match_glds(const uint16_t* __restrict__ ap, const uint16_t* __restrict__ bp,
+                                                             int na, int nb, int D, int jsplit,
+                                                             unsigned long long* __restrict__ best /*[na]*/) {
+    extern __shared__ __attribute__((aligned(1024))) char tg_smem[];
+    typedef tome_f16x8 vec;
+    constexpr int QI = 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave & 1, wj = wave >> 1;
+    const int itile = blockIdx.x / jsplit, jpart = blockIdx.x % jsplit;
+    const int i0 = itile * TG_T;
+    const int jtiles = (nb + TG_T - 1) / TG_T;
+    const int jt_lo = (int)((long long)jtiles * jpart / jsplit), jt_hi = (int)((long long)jtiles * (jpart + 1) / jsplit);
+    const int lcol = lane & 31, lhalf = lane >> 5;
+
+    // copy plan: wave w issues pieces g = w + 8 c, c = 0..7 (1 KB = 16 rows x 64 B each): g < 32 -> A, else B; plane = (g >> 4) & 1,
+    // rows (g & 15) * 16 + lane / 4, chunk position lane & 3 <- source chunk (lane & 3) ^ ((lane >> 4) & 3)
+    const int prow = lane >> 2, src_chunk = (lane & 3) ^ ((lane >> 4) & 3);
+    const char* asrc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int g = wave + 8 * c, plane = (g >> 4) & 1, row = (g & 15) * 16 + prow;
+        asrc[c] = reinterpret_cast<const char*>(ap + ((int64_t)plane * na + min(i0 + row, na - 1)) * D + src_chunk * 8);
+    }
+    auto issue = [&](int buf, int j0, int k0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int g = wave + 8 * c;
+            __builtin_amdgcn_global_load_lds((tome_gptr)(asrc[c] + (int64_t)k0 * 2), (tome_lptr)(tg_smem + buf * TG_BUF + g * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int c = 4; c < 8; ++c) {
+            const int g = wave + 8 * c, plane = (g >> 4) & 1, row = (g & 15) * 16 + prow;
+            const char* src = reinterpret_cast<const char*>(bp + ((int64_t)plane * nb + min(j0 + row, nb - 1)) * D + k0 + src_chunk * 8);
+            __builtin_amdgcn_global_load_lds((tome_gptr)src, (tome_lptr)(tg_smem + buf * TG_BUF + g * 1024), 16, 0, 0);
+        }
+    };
+    // fragment addresses: row * 64 + (chunk ^ swizzle) * 16, chunk = ks / 8 + lhalf
+    const int sw = (lcol >> 2) & 3;
+    const int a_off = (wi * 128 + lcol) * 64, b_off = 2 * TG_PLANE + (wj * 64 + lcol) * 64;
+
+    float bestv[QI];
+    int bestj[QI];
+#pragma unroll
+    for (int q = 0; q < QI; ++q) { bestv[q] = -INFINITY; bestj[q] = 0x7fffffff; }
+    int cur = 0;
+    if (jt_lo < jt_hi) issue(0, jt_lo * TG_T, 0);
+    for (int jt = jt_lo; jt < jt_hi; ++jt) {
+        const int j0 = jt * TG_T;
+        f32x16_t acc[2][QI];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = 0; q < QI; ++q)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[p][q][e] = 0.f;
+        for (int k0 = 0; k0 < D; k0 += TG_KS) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of the current stage have landed
+            __syncthreads();                                       // ... everyone's have, and the other buffer is no longer read
+            if (k0 + TG_KS < D) issue(cur ^ 1, j0, k0 + TG_KS);
+            else if (jt + 1 < jt_hi) issue(cur ^ 1, j0 + TG_T, 0);
+            const char* base = tg_smem + cur * TG_BUF;
+#pragma unroll
+            for (int ks = 0; ks < TG_KS; ks += 16) {
+                const int coff = (((ks >> 3) + lhalf) ^ sw) * 16;
+                vec fb[2][2], fa[QI][2];      // [subtile][plane: 0 = h, 1 = l]
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+                        fb[p][pl] = *reinterpret_cast<const vec*>(base + b_off + pl * TG_PLANE + p * 32 * 64 + coff);
+#pragma unroll
+                    for (int q = 0; q < QI; ++q)
+                        fa[q][pl] = *reinterpret_cast<const vec*>(base + a_off + pl * TG_PLANE + q * 32 * 64 + coff);
+                }
+#pragma unroll
+                for (int term = 4 - TERMS; term < 4; ++term) {
+                    const int pb = term == 0 || term == 1, pa = term == 0 || term == 2;    // l.l, l.h, h.l, h.h
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+#pragma unroll
+                        for (int q = 0; q < QI; ++q)
+                            acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[p][pb], fa[q][pa], acc[p][q], 0, 0, 0);
+                }
+            }
+            cur ^= 1;
+        }
+#pragma unroll
+        for (int q = 0; q < QI; ++q)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int j = j0 + wj * 64 + p * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
+                    const float v = acc[p][q][e];
+                    if (j < nb && (v > bestv[q] || (v == bestv[q] && j < bestj[q]))) { bestv[q] = v; bestj[q] = j; }
+                }
+    }
+#pragma unroll
+    for (int q = 0; q < QI; ++q) {
+        const int i = i0 + wi * 128 + q * 32 + lcol;
+        if (i < na && bestj[q] != 0x7fffffff) atomicMax(best + i, pack_score(bestv[q] * kSplitUnscale, bestj[q]));
     }
 }
 
@@ -369,7 +665,26 @@ __global__ void k_tome_fill(const int* __restrict__ order, const int* __restrict
 // one wave per output row.  rows [0, na - r): unmerged a-tokens in rank order; rows [na - r, n - r): b-tokens.
 // Every tensor of the reference is rounded to the input dtype T (x * size, the scatter-added sums, the sums of sizes, the
 // quotient): for T = float that is the plain fp32 arithmetic of the reference, without contraction.
-template <typename T>
+template <typename T, int VEC> __device__ __forceinline__ void tome_ld_vec(const void* x, int64_t off, float (&v)[VEC]) {
+    if constexpr (VEC == 1) {
+        v[0] = tome_ld<T>(x, off);
+    } else {
+        const Pack<T, VEC> p = load_pack<T, VEC>(x, off);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] = p.get(e);
+    }
+}
+template <typename T, int VEC> __device__ __forceinline__ void tome_st_vec(void* x, int64_t off, const float (&v)[VEC]) {
+    if constexpr (VEC == 1) {
+        tome_st<T>(x, off, v[0]);
+    } else {
+        Pack<T, VEC> p;
+        pack_fill<T, VEC>(p, [&](int e) { return v[e]; });
+        store_pack<T, VEC>(x, off, p);
+    }
+}
+// VEC channels per lane and step (VEC * sizeof(T) bytes per access); the per-element arithmetic does not depend on VEC.
+template <typename T, int VEC>
 __global__ void __launch_bounds__(256) k_tome_merge(const void* __restrict__ x, const float* __restrict__ size,
                                                     const int64_t* __restrict__ idx, int n, int C, int na, int nb, int r,
                                                     const int* __restrict__ order, const int* __restrict__ off,
@@ -383,8 +698,13 @@ __global__ void __launch_bounds__(256) k_tome_merge(const void* __restrict__ x, 
         if (row < na - r) {
             const int tok = 2 * order[r + row];                   // unmerged a-token: (x*size)/size
             const float s = size ? size[tok] : 1.f;
-            for (int c = lane; c < C; c += 64)
-                tome_st<T>(x_out, (int64_t)row * C + c, tome_round<T>(tome_ld<T>(x, (int64_t)tok * C + c) * s) / s);
+            for (int c = lane * VEC; c < C; c += 64 * VEC) {
+                float v[VEC];
+                tome_ld_vec<T, VEC>(x, (int64_t)tok * C + c, v);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[e] = tome_round<T>(v[e] * s) / s;
+                tome_st_vec<T, VEC>(x_out, (int64_t)row * C + c, v);
+            }
             if (lane == 0) { size_out[row] = s; idx_out[row] = idx[tok]; }
             continue;
         }
@@ -421,14 +741,21 @@ __global__ void __launch_bounds__(256) k_tome_merge(const void* __restrict__ x, 
             stot = stot + (size ? size[atok] : 1.f);
         }
         stot = tome_round<T>(stot);
-        for (int c = lane; c < C; c += 64) {
-            float acc = tome_round<T>(tome_ld<T>(x, (int64_t)tok * C + c) * sb);     // plain operators: the __fmul_rn/__fadd_rn wrappers fuse once inlined
+        for (int c = lane * VEC; c < C; c += 64 * VEC) {
+            float acc[VEC], xa[VEC];
+            tome_ld_vec<T, VEC>(x, (int64_t)tok * C + c, acc);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] = tome_round<T>(acc[e] * sb);      // plain operators: the __fmul_rn/__fadd_rn wrappers fuse once inlined
             for (int m = 0; m < cnt; ++m) {
                 const int atok = 2 * order[lists[o + m]];
                 const float sa = size ? size[atok] : 1.f;
-                acc = acc + tome_round<T>(tome_ld<T>(x, (int64_t)atok * C + c) * sa);
+                tome_ld_vec<T, VEC>(x, (int64_t)atok * C + c, xa);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[e] = acc[e] + tome_round<T>(xa[e] * sa);
             }
-            tome_st<T>(x_out, (int64_t)row * C + c, tome_round<T>(acc) / stot);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] = tome_round<T>(acc[e]) / stot;
+            tome_st_vec<T, VEC>(x_out, (int64_t)row * C + c, acc);
         }
         if (lane == 0) { size_out[row] = stot; idx_out[row] = idx[tok]; }
     }
@@ -456,7 +783,7 @@ static inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
 static int tome_plan(int n, int C, int n_head, TomePlan* p) {
     if (n < 2 || C < 1 || n_head < 1 || C % n_head) return -1;
     p->na = (n + 1) / 2; p->nb = n / 2; p->D = C / n_head;
-    p->Dp = (p->D + TM_K - 1) / TM_K * TM_K;
+    p->Dp = (p->D + 63) / 64 * 64;                           // zero-padded to the widest k stage of the match kernels
     size_t o = 0;
     p->off_ahat = o; o = al(o + (size_t)p->na * p->Dp * 4);
     p->off_bhat = o; o = al(o + (size_t)(p->nb > 0 ? p->nb : 1) * p->Dp * 4);
@@ -517,22 +844,50 @@ int sttm_tome_step(const void* x_, const float* size, const int64_t* idx, int n,
     (void)hipMemsetAsync(best, 0, (size_t)p.na * 8, stream);
     (void)hipMemsetAsync(cnt, 0, p.off_off - p.off_cnt, stream);      // cnt and cur
     const int ngrid = [&] { int g = (n + 3) / 4; return g > 8192 ? 8192 : g; }();
-    const int itiles = (p.na + TM_I - 1) / TM_I;
-    const int jtiles = (p.nb + TM_J - 1) / TM_J;
-    // j-split: the grid is itiles*jsplit workgroups of ceil(jtiles/jsplit) tile products each, two resident per CU.
-    // Pick the split with the smallest per-CU critical path  ceil(WGs / CUs) * tiles-per-WG  (a 588-WG grid on 512
+    // j-split: the grid is itiles*jsplit workgroups of ceil(jtiles/jsplit) tile products each, `resident` per CU.
+    // Pick the split with the smallest per-CU critical path  ceil(WGs / slots) * tiles-per-WG  (a 588-WG grid on 512
     // slots leaves a third of the chip idle for the second round); ties go to the coarser split (fewer atomics).
     const int n_cu = tome_cu_count();
-    int jsplit = 1;
-    long best_cost = -1;
-    for (int js = 1; js <= jtiles; ++js) {
-        const long wgs = (long)itiles * js;
-        const long per_cu = (wgs + n_cu - 1) / n_cu;
-        long cost = per_cu * ((jtiles + js - 1) / js);
-        if (per_cu < 2 && js < jtiles) cost = cost * 3 / 2;       // a lone WG per CU cannot hide its staging
-        if (best_cost < 0 || cost < best_cost) { best_cost = cost; jsplit = js; }
-    }
-    if (dtype == STTM_F32) {
+    auto pick_jsplit = [&](int itiles, int tj, int resident) {
+        const int jtiles = (p.nb + tj - 1) / tj;
+        int jsplit = 1;
+        long best_cost = -1;
+        for (int js = 1; js <= jtiles; ++js) {
+            const long wgs = (long)itiles * js;
+            const long per_cu = (wgs + n_cu - 1) / n_cu;
+            long cost = per_cu * ((jtiles + js - 1) / js);
+            if (per_cu < resident && js < jtiles) cost = cost * 3 / 2;       // a lone WG of a resident pair cannot hide its staging
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; jsplit = js; }
+        }
+        return jsplit;
+    };
+    const int itiles = (p.na + TM_I - 1) / TM_I;
+    const int jsplit = pick_jsplit(itiles, TM_J, 2);
+    const int split = tome_split_mode();
+    if (dtype == STTM_F32 && split > 0) {
+        uint16_t* ap = reinterpret_cast<uint16_t*>(ahat);
+        uint16_t* bp = reinterpret_cast<uint16_t*>(bhat);
+        if (n_head == 1 && C % 4 == 0 && reinterpret_cast<uintptr_t>(x_) % 16 == 0)
+            hipLaunchKernelGGL(k_tome_normalize_split<4>, dim3(ngrid), dim3(256), 0, stream, reinterpret_cast<const float*>(x_), n, C,
+                               n_head, p.D, p.Dp, ap, p.na, bp, p.nb);
+        else
+            hipLaunchKernelGGL(k_tome_normalize_split<1>, dim3(ngrid), dim3(256), 0, stream, reinterpret_cast<const float*>(x_), n, C,
+                               n_head, p.D, p.Dp, ap, p.na, bp, p.nb);
+        // tome_split: 1 = four product terms, 2 = three (without l.l); 3/4 force the 128-tile / the 256-tile DMA kernel (4 terms),
+        // 5/6 the same with 3 terms.  The 256-tile kernel wins from ~6 k tokens on (measured cross-over: T = 32 frames of 196).
+        const int terms = (split == 2 || split == 5 || split == 6) ? 3 : 4;
+        const bool big = split == 4 || split == 6 || ((split == 1 || split == 2) && p.na >= 3072);
+        if (big) {
+            const int it = (p.na + TG_T - 1) / TG_T;
+            const int js = pick_jsplit(it, TG_T, 1);
+            if (terms == 4) hipLaunchKernelGGL(k_tome_match_glds<4>, dim3(it * js), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
+            else hipLaunchKernelGGL(k_tome_match_glds<3>, dim3(it * js), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
+        } else {
+            const size_t lds = (size_t)(2 * TM_I + 2 * TM_J) * (TM_K + 8) * 2;
+            if (terms == 4) hipLaunchKernelGGL((k_tome_match_split<TM_K, 2, 2, 4>), dim3(itiles * jsplit), dim3(256), lds, stream, ap, bp, p.na, p.nb, p.Dp, jsplit, best);
+            else hipLaunchKernelGGL((k_tome_match_split<TM_K, 2, 2, 3>), dim3(itiles * jsplit), dim3(256), lds, stream, ap, bp, p.na, p.nb, p.Dp, jsplit, best);
+        }
+    } else if (dtype == STTM_F32) {
         hipLaunchKernelGGL(k_tome_normalize, dim3(ngrid), dim3(256), 0, stream, reinterpret_cast<const float*>(x_), n, C, n_head, p.D, p.Dp, ahat, bhat);
         hipLaunchKernelGGL(k_tome_match, dim3(itiles * jsplit), dim3(256), 0, stream, ahat, bhat, p.na, p.nb, p.Dp, jsplit, best);
     } else if (dtype == STTM_BF16) {
@@ -554,8 +909,12 @@ int sttm_tome_step(const void* x_, const float* size, const int64_t* idx, int n,
     hipLaunchKernelGGL(k_tome_fill, dim3((r + 255) / 256), dim3(256), 0, stream, order, nidx, r, off, cur, lists);
     {
         int grid = (n - r + 3) / 4; if (grid > 8192) grid = 8192;
-#define STTM_TOME_MERGE(TT) hipLaunchKernelGGL(k_tome_merge<TT>, dim3(grid), dim3(256), 0, stream, x_, size, idx, n, C, p.na, p.nb, r, order, off, lists, x_out_, size_out, idx_out)
-        if (dtype == STTM_F32) STTM_TOME_MERGE(float); else if (dtype == STTM_BF16) STTM_TOME_MERGE(bf16_t); else STTM_TOME_MERGE(f16_t);
+#define STTM_TOME_MERGE(TT, VV) hipLaunchKernelGGL((k_tome_merge<TT, VV>), dim3(grid), dim3(256), 0, stream, x_, size, idx, n, C, p.na, p.nb, r, order, off, lists, x_out_, size_out, idx_out)
+        const size_t eb = dtype == STTM_F32 ? 4 : 2;
+        const bool v4 = C % 4 == 0 && reinterpret_cast<uintptr_t>(x_) % (4 * eb) == 0 && reinterpret_cast<uintptr_t>(x_out_) % (4 * eb) == 0;
+        if (dtype == STTM_F32) { if (v4) STTM_TOME_MERGE(float, 4); else STTM_TOME_MERGE(float, 1); }
+        else if (dtype == STTM_BF16) { if (v4) STTM_TOME_MERGE(bf16_t, 4); else STTM_TOME_MERGE(bf16_t, 1); }
+        else { if (v4) STTM_TOME_MERGE(f16_t, 4); else STTM_TOME_MERGE(f16_t, 1); }
 #undef STTM_TOME_MERGE
     }
     if (node_max_out) (void)hipMemcpyAsync(node_max_out, nmax, (size_t)p.na * 4, hipMemcpyDeviceToDevice, stream);

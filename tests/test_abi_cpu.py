@@ -134,7 +134,7 @@ def test_product_library_has_no_measurement_hooks():
     lib = _lib.load()
     assert not hasattr(lib, "sttm_dev_hooks")
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sttm_amd", "csrc", "api.hip")).read()
-    body = src[src.index("int merge_group("):src.index("}  // namespace\n\nextern")]
+    body = src[src.index("int merge_group("):src.index("}  // namespace\n")]
     assert "getenv" not in body          # tuning switches are read once (config()), never per call
 
 

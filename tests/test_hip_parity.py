@@ -554,6 +554,62 @@ def test_tome_match_scores_against_dense_reference():
     assert agree > 0.999
 
 
+TOME_MATCH_MODES = {"fp32_mfma": 0, "split4_tile128": 3, "split4_tile256_dma": 4, "split3_tile128": 5, "split3_tile256_dma": 6}
+
+
+@pytest.mark.parametrize("mode", sorted(TOME_MATCH_MODES), ids=str)
+def test_tome_match_kernel_variants(mode):
+    """Every match kernel of the fp32 path on the same inputs (the default picks one by size, csrc/tome.hip): the fp32-input
+    MFMA kernel, and the fp16 two-plane split on the 128-tile kernel and on the 256-tile LDS-DMA kernel, with 4 and 3 product
+    terms -- golden vectors, oracle cases (odd C, several heads, a clip smaller than one tile) and the best scores against a
+    float64 product."""
+    from oracle import sttm_oracle as O
+    from sttm_amd import _lib, get_tome_features
+    from sttm_amd.synth import synth_video
+    lib = _lib.load()
+    dev = _dev()
+    _lib.configure(tome_split=TOME_MATCH_MODES[mode])
+    try:
+        for path in case_paths(["tome_"]):
+            c = load_case(path)
+            m = c["meta"]
+            feat, idx = get_tome_features(c["x"].to(dev), m["ratio"], "video", m["n_head"])
+            gi, gf = _tome_as_map(feat.cpu(), idx.cpu())
+            ei, ef = _tome_as_map(c["feat"], c["idx"])
+            assert torch.equal(gi, ei), f"{mode} {c['name']}: kept token ids differ"
+            assert float((gf - ef).abs().max()) <= FP32_TOL
+        for T, C, ratio, n_head in [(8, 1024, 0.7, 1), (16, 1024, 0.85, 1), (6, 512, 0.7, 4), (5, 1000, 0.3, 1), (1, 1024, 0.5, 1),
+                                    (23, 96, 0.6, 1)]:
+            x = synth_video(T, C, 14, 14, seed=50 + T)
+            ef, ei = O.get_tome_features(x, ratio, "video", n_head)
+            f, i = get_tome_features(x.to(dev), ratio, "video", n_head)
+            _compare_tome(f, i, ef, ei, FP32_TOL, f"{mode} T={T} C={C} r={ratio}")
+        # best scores / argmax of one step against a float64 product (3 clips: below one tile, ragged, several tiles)
+        for T in (1, 7, 24):
+            x = synth_video(T, 1024, 14, 14, seed=60 + T).permute(0, 2, 3, 1).reshape(-1, 1024).contiguous().to(dev)
+            n, C = x.shape
+            r = n // 2
+            nbytes = lib.sttm_tome_workspace_bytes(n, C, 1)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            xo = torch.empty((n - r, C), device=dev); so = torch.empty(n - r, device=dev); io = torch.empty(n - r, dtype=torch.int64, device=dev)
+            nmax = torch.empty((n + 1) // 2, device=dev); nidx = torch.empty((n + 1) // 2, dtype=torch.int32, device=dev)
+            idx = torch.arange(n, device=dev)
+            rc = lib.sttm_tome_step(x.data_ptr(), None, idx.data_ptr(), n, C, 1, r, 0, ws.data_ptr(), nbytes, xo.data_ptr(),
+                                    so.data_ptr(), io.data_ptr(), nmax.data_ptr(), nidx.data_ptr(),
+                                    torch.cuda.current_stream().cuda_stream)
+            _lib.raise_for(rc)
+            torch.cuda.synchronize()
+            u = (x / x.norm(dim=-1, keepdim=True)).double()
+            scores = u[0::2] @ u[1::2].T
+            ref_max, ref_idx = scores.max(-1)
+            err = float((nmax.double() - ref_max).abs().max())
+            agree = (nidx.long() == ref_idx).float().mean().item()
+            print(f"{mode} T={T}: max |best score - float64| {err:.3e}, argmax agreement {agree:.5f}")
+            assert err < 2e-6 and agree > 0.999
+    finally:
+        _lib.configure(tome_split=1)
+
+
 @pytest.mark.parametrize("case", [c for c in kat()["errors"] if c["fn"] == "tome"], ids=lambda c: c["name"])
 def test_tome_error_behaviour_matches_reference(case):
     from sttm_amd import get_tome_features
