@@ -155,9 +155,9 @@ int sttm_quadtree_merge_batch(int n_videos, const void* const* x, int64_t stride
  *   "no_fuse"     1: stand-alone label stage as two launches (no in-kernel grid barrier)
  *   "force_gmem_labels"  1: label stage on global scratch instead of LDS (the path of columns too large for LDS)
  *   "tome_split"  ToMe match kernel for float32 inputs.  1 (default): unit rows as two fp16 planes (h + l of 4096 v, residual
- *                 <= 2^-24), scores from the products l.l + l.h + h.l + h.h on the fp16 matrix pipe with fp32 accumulation
- *                 (each product exact; error bound 1.2e-7 + the fp32 accumulation, measured <= 9.2e-7 against float64 where
- *                 the fp32-input MFMA kernel measures 1.4e-6), kernel picked by size; 2: the same without l.l (bound 3.6e-7);
+ *                 <= 2^-23), scores from the products l.l + l.h + h.l + h.h on the fp16 matrix pipe with fp32 accumulation
+ *                 (each product exact; error bound 2.4e-7 + the fp32 accumulation, measured <= 9.2e-7 against float64 where
+ *                 the fp32-input MFMA kernel measures 1.4e-6), kernel picked by size; 2: the same without l.l (bound 4.8e-7);
  *                 0: fp32-input MFMA (v_mfma_f32_32x32x2_f32), 2.9x slower; 3 / 4: force the 128-tile / 256-tile kernel, 5 / 6
  *                 the same with three terms (tests)
  */

@@ -312,13 +312,15 @@ __global__ void __launch_bounds__(256, 2) k_tome_match16(const uint16_t* __restr
 
 // ---------------------------------------------------------------------------------------------------
 // fp32 inputs on the 16-bit matrix pipe (16x the rate of v_mfma_f32_32x32x2_f32): every unit-row element v is written as
-//     4096 * v = h + l,   h = fp16(4096 v),  l = fp16(4096 v - h)        (|v| <= 1: no overflow; the scale keeps l normal)
-// which leaves |4096 v - h - l| <= 2^-24 |4096 v| (two round-to-nearest steps), and the score is accumulated in fp32 from
-// the four products  l.l + l.h + h.l + h.h  (each fp16 x fp16 product is exact in fp32), times 2^-24 at the end.
-// Error of one score against the real dot product of the fp32 rows: <= 2 * 2^-24 * sum|a_k b_k| <= 1.2e-7 from the split
-// (Cauchy-Schwarz, unit rows) plus the fp32 accumulation, i.e. the same order as an fp32 FMA chain over k = 1024 (measured
-// on the test clips: max |error| 6.1e-7 against 4.7e-7 for sgemm, no argmax change).  The reference's own result is only
-// defined up to that accumulation order (cuBLAS / MKL sgemm).  Same tile structure as k_tome_match16.
+//     4096 * v = h + l + e,   h = fp16(4096 v),  l = fp16(4096 v - h)     (|v| <= 1: no overflow; the scale keeps l normal)
+// 4096 v - h is exact in fp32 and has at most 13 significant bits below h's last place, of which l keeps 11: |e| <= 2^-23 |4096 v|
+// (zero for most elements).  The score is accumulated in fp32 from the four products  l.l + l.h + h.l + h.h  (every
+// fp16 x fp16 product is exact in fp32) and multiplied by 2^-24 at the end.
+// Error of one score against the real dot product of the fp32 rows: <= 2 * 2^-23 * sum|a_k b_k| <= 2.4e-7 from e
+// (Cauchy-Schwarz, unit rows; three terms drop l.l: + 2^-22, 4.8e-7 in all) plus the fp32 accumulation of the partial sums --
+// the same order as any fp32 FMA chain over k = 1024.  Measured on the 128-frame test clip against a float64 product: max
+// |error| 9.1e-7 with four AND with three terms, 1.37e-6 for the fp32-input MFMA kernel above, no argmax change in 12 544
+// rows.  The reference's own scores are only defined up to that accumulation order (cuBLAS / MKL sgemm).
 // ---------------------------------------------------------------------------------------------------
 constexpr float kSplitScale = 4096.f;
 constexpr float kSplitUnscale = 1.f / (4096.f * 4096.f);
@@ -485,27 +487,37 @@ __global__ void __launch_bounds__(128 * WJ, 2) k_tome_match_split(const uint16_t
     }
 }
 
-// The same product on a 256 x 256 workgroup tile (8 waves of 64 (j) x 128 (i), one workgroup per CU) with the operand tiles
-// copied global -> LDS by the DMA path (global_load_lds_dwordx4: no staging registers, no ds_write pass) into two LDS buffers:
-// the copy of stage s+1 runs under the MFMAs of stage s, one barrier per stage.  A stage is 32 k of both planes of both
-// matrices = 64 KB (2 x 64 KB buffers of the 160 KB LDS); LDS reads per MFMA are 2/3 of the 128 x 128 kernel's.
-// An LDS-DMA instruction writes wave-linear (base + lane * 16 bytes), so rows are unpadded (64 bytes) and the bank spread comes
-// from a chunk swizzle applied to the SOURCE address: 16-byte chunk c of tile row r lives at chunk position c ^ ((r >> 2) & 3),
-// which sends the 16 rows of a ds_read_b128 lane group to 16 different 4-bank groups.
+// The match on a 256 x 256 workgroup tile (8 waves of 64 (j) x 128 (i), one workgroup per CU) with the operand tiles copied
+// global -> LDS by the DMA path (global_load_lds_dwordx4: no staging registers, no ds_write pass) into two LDS buffers: the
+// copy of stage s+1 runs under the MFMAs of stage s, one barrier per stage.  A stage is 64 KB (2 x 64 KB buffers of the
+// 160 KB LDS): 32 k of both planes of both matrices for the fp16 split of fp32 inputs (NP = 2), 64 k of both matrices for
+// bf16 / fp16 inputs (NP = 1).  LDS reads per MFMA are 2/3 of the 128 x 128 kernels'.
+// An LDS-DMA instruction writes wave-linear (base + lane * 16 bytes), so rows are unpadded (64 / 128 bytes) and the bank spread
+// comes from a chunk swizzle applied to the SOURCE address: 16-byte chunk c of tile row r lives at chunk position
+// c ^ ((r / rows-per-256-bytes) & (chunks-per-row - 1)), which sends the 16 rows of a ds_read_b128 lane group to 16 different
+// 4-bank groups.
 typedef const __attribute__((address_space(1))) void* tome_gptr;
 typedef __attribute__((address_space(3))) void* tome_lptr;
 constexpr int TG_T = 256;                       // tile side
-constexpr int TG_KS = 32;                       // k per stage
-constexpr int TG_PLANE = TG_T * TG_KS * 2;      // bytes of one plane of one matrix tile (16 KB)
-constexpr int TG_BUF = 4 * TG_PLANE;            // A.h, A.l, B.h, B.l
+constexpr int TG_BUF = 65536;                   // bytes of one stage: [matrix A, B][plane][256 rows][KS * 2 bytes]
 
-template <int TERMS>
+// NP = 2: fp32 inputs as two fp16 planes, TERMS = 4 / 3 products per k (T = f16_t).  NP = 1: 16-bit inputs of type T, one
+// product, scores rounded to T before the comparison (the reference's score tensor has the input dtype).
+template <int NP, int TERMS, typename T>
 __global__ void __launch_bounds__(512, 2) k_tome_match_glds(const uint16_t* __restrict__ ap, const uint16_t* __restrict__ bp,
                                                              int na, int nb, int D, int jsplit,
                                                              unsigned long long* __restrict__ best /*[na]*/) {
+    static_assert((NP == 2 && (TERMS == 3 || TERMS == 4)) || (NP == 1 && TERMS == 1), "plane / term combination");
     extern __shared__ __attribute__((aligned(1024))) char tg_smem[];
-    typedef tome_f16x8 vec;
+    typedef typename TomeMfma<T>::vec vec;
     constexpr int QI = 4;
+    constexpr int KS = 64 / NP;                  // k per stage
+    constexpr int RB = KS * 2;                   // bytes per tile row
+    constexpr int CPR = RB / 16;                 // 16-byte chunks per row
+    constexpr int RPP = 1024 / RB;               // rows per 1 KB piece
+    constexpr int PPM = TG_T / RPP;              // pieces per plane of one matrix tile
+    constexpr int PLANE = TG_T * RB;             // bytes of one plane of one matrix tile
+    constexpr int R256 = 256 / RB;               // rows per 256 bytes of LDS (the bank period)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wave & 1, wj = wave >> 1;
@@ -515,14 +527,16 @@ __global__ void __launch_bounds__(512, 2) k_tome_match_glds(const uint16_t* __re
     const int jt_lo = (int)((long long)jtiles * jpart / jsplit), jt_hi = (int)((long long)jtiles * (jpart + 1) / jsplit);
     const int lcol = lane & 31, lhalf = lane >> 5;
 
-    // copy plan: wave w issues pieces g = w + 8 c, c = 0..7 (1 KB = 16 rows x 64 B each): g < 32 -> A, else B; plane = (g >> 4) & 1,
-    // rows (g & 15) * 16 + lane / 4, chunk position lane & 3 <- source chunk (lane & 3) ^ ((lane >> 4) & 3)
-    const int prow = lane >> 2, src_chunk = (lane & 3) ^ ((lane >> 4) & 3);
+    // copy plan: wave w issues pieces g = w + 8 c, c = 0..7; pieces 0..31 are A (plane-major), 32..63 B.  Piece g holds rows
+    // (g % PPM) * RPP + lane / CPR of plane (g / PPM) % NP at chunk position lane % CPR
+    const int prow = lane / CPR;
+    auto piece_row = [&](int g) { return (g % PPM) * RPP + prow; };
+    auto src_chunk = [&](int g) { return (lane % CPR) ^ ((piece_row(g) / R256) & (CPR - 1)); };
     const char* asrc[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const int g = wave + 8 * c, plane = (g >> 4) & 1, row = (g & 15) * 16 + prow;
-        asrc[c] = reinterpret_cast<const char*>(ap + ((int64_t)plane * na + min(i0 + row, na - 1)) * D + src_chunk * 8);
+        const int g = wave + 8 * c, plane = (g / PPM) % NP;
+        asrc[c] = reinterpret_cast<const char*>(ap + ((int64_t)plane * na + min(i0 + piece_row(g), na - 1)) * D + src_chunk(g) * 8);
     }
     auto issue = [&](int buf, int j0, int k0) {
 #pragma unroll
@@ -532,14 +546,14 @@ __global__ void __launch_bounds__(512, 2) k_tome_match_glds(const uint16_t* __re
         }
 #pragma unroll
         for (int c = 4; c < 8; ++c) {
-            const int g = wave + 8 * c, plane = (g >> 4) & 1, row = (g & 15) * 16 + prow;
-            const char* src = reinterpret_cast<const char*>(bp + ((int64_t)plane * nb + min(j0 + row, nb - 1)) * D + k0 + src_chunk * 8);
+            const int g = wave + 8 * c, plane = (g / PPM) % NP;
+            const char* src = reinterpret_cast<const char*>(bp + ((int64_t)plane * nb + min(j0 + piece_row(g), nb - 1)) * D + k0 + src_chunk(g) * 8);
             __builtin_amdgcn_global_load_lds((tome_gptr)src, (tome_lptr)(tg_smem + buf * TG_BUF + g * 1024), 16, 0, 0);
         }
     };
-    // fragment addresses: row * 64 + (chunk ^ swizzle) * 16, chunk = ks / 8 + lhalf
-    const int sw = (lcol >> 2) & 3;
-    const int a_off = (wi * 128 + lcol) * 64, b_off = 2 * TG_PLANE + (wj * 64 + lcol) * 64;
+    // fragment addresses: row * RB + (chunk ^ swizzle) * 16, chunk = ks / 8 + lhalf (the subtile bases are multiples of 32 rows)
+    const int sw = (lcol / R256) & (CPR - 1);
+    const int a_off = (wi * 128 + lcol) * RB, b_off = NP * PLANE + (wj * 64 + lcol) * RB;
 
     float bestv[QI];
     int bestj[QI];
@@ -556,37 +570,39 @@ __global__ void __launch_bounds__(512, 2) k_tome_match_glds(const uint16_t* __re
             for (int q = 0; q < QI; ++q)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[p][q][e] = 0.f;
-        for (int k0 = 0; k0 < D; k0 += TG_KS) {
+        for (int k0 = 0; k0 < D; k0 += KS) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of the current stage have landed
             __syncthreads();                                       // ... everyone's have, and the other buffer is no longer read
-            if (k0 + TG_KS < D) issue(cur ^ 1, j0, k0 + TG_KS);
+            if (k0 + KS < D) issue(cur ^ 1, j0, k0 + KS);
             else if (jt + 1 < jt_hi) issue(cur ^ 1, j0 + TG_T, 0);
             const char* base = tg_smem + cur * TG_BUF;
 #pragma unroll
-            for (int ks = 0; ks < TG_KS; ks += 16) {
+            for (int ks = 0; ks < KS; ks += 16) {
                 const int coff = (((ks >> 3) + lhalf) ^ sw) * 16;
-                vec fb[2][2], fa[QI][2];      // [subtile][plane: 0 = h, 1 = l]
+                vec fb[2][NP], fa[QI][NP];      // [subtile][plane: 0 = h, 1 = l]
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl) {
+                for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
                     for (int p = 0; p < 2; ++p)
-                        fb[p][pl] = *reinterpret_cast<const vec*>(base + b_off + pl * TG_PLANE + p * 32 * 64 + coff);
+                        fb[p][pl] = *reinterpret_cast<const vec*>(base + b_off + pl * PLANE + p * 32 * RB + coff);
 #pragma unroll
                     for (int q = 0; q < QI; ++q)
-                        fa[q][pl] = *reinterpret_cast<const vec*>(base + a_off + pl * TG_PLANE + q * 32 * 64 + coff);
+                        fa[q][pl] = *reinterpret_cast<const vec*>(base + a_off + pl * PLANE + q * 32 * RB + coff);
                 }
 #pragma unroll
                 for (int term = 4 - TERMS; term < 4; ++term) {
-                    const int pb = term == 0 || term == 1, pa = term == 0 || term == 2;    // l.l, l.h, h.l, h.h
+                    // l.l, l.h, h.l, h.h (small terms first); one plane: the only term is h.h
+                    const int pb = NP == 2 && (term == 0 || term == 1), pa = NP == 2 && (term == 0 || term == 2);
 #pragma unroll
                     for (int p = 0; p < 2; ++p)
 #pragma unroll
                         for (int q = 0; q < QI; ++q)
-                            acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[p][pb], fa[q][pa], acc[p][q], 0, 0, 0);
+                            acc[p][q] = TomeMfma<T>::run(fb[p][pb], fa[q][pa], acc[p][q]);
                 }
             }
             cur ^= 1;
         }
+        // running max over this tile.  Split: on the scaled scores (the factor 2^-24 is applied once, at the end)
 #pragma unroll
         for (int q = 0; q < QI; ++q)
 #pragma unroll
@@ -594,14 +610,14 @@ __global__ void __launch_bounds__(512, 2) k_tome_match_glds(const uint16_t* __re
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int j = j0 + wj * 64 + p * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
-                    const float v = acc[p][q][e];
+                    const float v = NP == 1 ? tome_round<T>(acc[p][q][e]) : acc[p][q][e];
                     if (j < nb && (v > bestv[q] || (v == bestv[q] && j < bestj[q]))) { bestv[q] = v; bestj[q] = j; }
                 }
     }
 #pragma unroll
     for (int q = 0; q < QI; ++q) {
         const int i = i0 + wi * 128 + q * 32 + lcol;
-        if (i < na && bestj[q] != 0x7fffffff) atomicMax(best + i, pack_score(bestv[q] * kSplitUnscale, bestj[q]));
+        if (i < na && bestj[q] != 0x7fffffff) atomicMax(best + i, pack_score(NP == 2 ? bestv[q] * kSplitUnscale : bestv[q], bestj[q]));
     }
 }
 
@@ -880,8 +896,8 @@ int sttm_tome_step(const void* x_, const float* size, const int64_t* idx, int n,
         if (big) {
             const int it = (p.na + TG_T - 1) / TG_T;
             const int js = pick_jsplit(it, TG_T, 1);
-            if (terms == 4) hipLaunchKernelGGL(k_tome_match_glds<4>, dim3(it * js), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
-            else hipLaunchKernelGGL(k_tome_match_glds<3>, dim3(it * js), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
+            if (terms == 4) hipLaunchKernelGGL((k_tome_match_glds<2, 4, f16_t>), dim3(it * js), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
+            else hipLaunchKernelGGL((k_tome_match_glds<2, 3, f16_t>), dim3(it * js), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
         } else {
             const size_t lds = (size_t)(2 * TM_I + 2 * TM_J) * (TM_K + 8) * 2;
             if (terms == 4) hipLaunchKernelGGL((k_tome_match_split<TM_K, 2, 2, 4>), dim3(itiles * jsplit), dim3(256), lds, stream, ap, bp, p.na, p.nb, p.Dp, jsplit, best);
@@ -890,16 +906,22 @@ int sttm_tome_step(const void* x_, const float* size, const int64_t* idx, int n,
     } else if (dtype == STTM_F32) {
         hipLaunchKernelGGL(k_tome_normalize, dim3(ngrid), dim3(256), 0, stream, reinterpret_cast<const float*>(x_), n, C, n_head, p.D, p.Dp, ahat, bhat);
         hipLaunchKernelGGL(k_tome_match, dim3(itiles * jsplit), dim3(256), 0, stream, ahat, bhat, p.na, p.nb, p.Dp, jsplit, best);
-    } else if (dtype == STTM_BF16) {
-        hipLaunchKernelGGL(k_tome_normalize16<bf16_t>, dim3(ngrid), dim3(256), 0, stream, x_, n, C, n_head, p.D, p.Dp,
-                           reinterpret_cast<uint16_t*>(ahat), reinterpret_cast<uint16_t*>(bhat));
-        hipLaunchKernelGGL(k_tome_match16<bf16_t>, dim3(itiles * jsplit), dim3(256), 0, stream, reinterpret_cast<const uint16_t*>(ahat),
-                           reinterpret_cast<const uint16_t*>(bhat), p.na, p.nb, p.Dp, jsplit, best);
     } else {
-        hipLaunchKernelGGL(k_tome_normalize16<f16_t>, dim3(ngrid), dim3(256), 0, stream, x_, n, C, n_head, p.D, p.Dp,
-                           reinterpret_cast<uint16_t*>(ahat), reinterpret_cast<uint16_t*>(bhat));
-        hipLaunchKernelGGL(k_tome_match16<f16_t>, dim3(itiles * jsplit), dim3(256), 0, stream, reinterpret_cast<const uint16_t*>(ahat),
-                           reinterpret_cast<const uint16_t*>(bhat), p.na, p.nb, p.Dp, jsplit, best);
+        // 16-bit inputs: the 256-tile DMA kernel from ~6 k tokens on ("tome_split" 3 / 5 force the 128-tile kernel, 4 / 6 the
+        // 256-tile one), like the split path
+        uint16_t* ap = reinterpret_cast<uint16_t*>(ahat);
+        uint16_t* bp = reinterpret_cast<uint16_t*>(bhat);
+        const bool big = split == 4 || split == 6 || (split != 3 && split != 5 && p.na >= 3072);
+        const int it = (p.na + TG_T - 1) / TG_T;
+        const int js = pick_jsplit(it, TG_T, 1);
+#define STTM_TOME_16(TT)                                                                                                            \
+        do {                                                                                                                        \
+            hipLaunchKernelGGL(k_tome_normalize16<TT>, dim3(ngrid), dim3(256), 0, stream, x_, n, C, n_head, p.D, p.Dp, ap, bp);       \
+            if (big) hipLaunchKernelGGL((k_tome_match_glds<1, 1, TT>), dim3(it * js), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best); \
+            else hipLaunchKernelGGL(k_tome_match16<TT>, dim3(itiles * jsplit), dim3(256), 0, stream, ap, bp, p.na, p.nb, p.Dp, jsplit, best); \
+        } while (0)
+        if (dtype == STTM_BF16) STTM_TOME_16(bf16_t); else STTM_TOME_16(f16_t);
+#undef STTM_TOME_16
     }
     hipLaunchKernelGGL(k_tome_unpack, dim3((p.na + 255) / 256), dim3(256), 0, stream, best, p.na, nmax, nidx, iota);
     size_t cub = p.cub_bytes;

@@ -610,6 +610,56 @@ def test_tome_match_kernel_variants(mode):
         _lib.configure(tome_split=1)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
+def test_tome_tile128_and_tile256_kernels_are_bit_identical(dtype):
+    """The 128-tile and the 256-tile LDS-DMA match kernels add the same products in the same order into one fp32 accumulator:
+    forcing either must give the same bits (features, ids, best scores) -- on a clip smaller than a tile, a ragged one and one
+    with several tiles per side, 4 and 3 product terms for fp32."""
+    from sttm_amd import _lib, get_tome_features
+    from sttm_amd.synth import synth_video
+    dev = _dev()
+    pairs = [(3, 4), (5, 6)] if dtype == torch.float32 else [(3, 4)]
+    try:
+        for T, C, ratio in [(1, 1024, 0.5), (7, 1000, 0.7), (40, 1024, 0.85), (12, 3584, 0.6)]:
+            if dtype != torch.float32 and C % 2:
+                continue
+            x = synth_video(T, C, 14, 14, seed=400 + T, dtype=dtype).to(dev)
+            for small, big in pairs:
+                _lib.configure(tome_split=small)
+                fa, ia = get_tome_features(x, ratio, "video")
+                _lib.configure(tome_split=big)
+                fb, ib = get_tome_features(x, ratio, "video")
+                assert torch.equal(ia, ib) and torch.equal(fa, fb), f"{dtype} T={T} C={C} r={ratio}: kernels {small} / {big} differ"
+    finally:
+        _lib.configure(tome_split=1)
+
+
+@pytest.mark.parametrize("mode", [3, 4], ids=["tile128", "tile256_dma"])
+def test_tome_16bit_match_kernel_variants(mode):
+    """Both 16-bit match kernels against the reference's vectors (bf16 / fp16 golden cases) and the oracle."""
+    from oracle import sttm_oracle as O
+    from sttm_amd import _lib, get_tome_features
+    from sttm_amd.synth import synth_video
+    _lib.configure(tome_split=mode)
+    try:
+        for path in case_paths(["tome16_"]):
+            c = load_case(path)
+            m = c["meta"]
+            feat, idx = get_tome_features(c["x"].to(_dev()), m["ratio"], "video", m["n_head"])
+            ida, fa = _tome16_agreement(feat, idx, c["feat"], c["idx"], f"{mode} {c['name']}")
+            if m["ratio"] == 0.5:
+                assert torch.equal(idx.cpu(), c["idx"])
+            assert ida >= 0.97 and fa >= 0.97
+        for dtype in (torch.bfloat16, torch.float16):
+            x = synth_video(32, 1024, 14, 14, seed=332, dtype=dtype)
+            ef, ei = O.get_tome_features(x, 0.7, "video", 1)
+            f, i = get_tome_features(x.to(_dev()), 0.7, "video", 1)
+            ida, fa = _tome16_agreement(f, i, ef, ei, f"{mode} {dtype}")
+            assert ida >= 0.97 and fa >= 0.97
+    finally:
+        _lib.configure(tome_split=1)
+
+
 @pytest.mark.parametrize("case", [c for c in kat()["errors"] if c["fn"] == "tome"], ids=lambda c: c["name"])
 def test_tome_error_behaviour_matches_reference(case):
     from sttm_amd import get_tome_features
