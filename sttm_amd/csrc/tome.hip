@@ -64,6 +64,16 @@ __device__ __forceinline__ unsigned long long pack_score(float v, int j) {
     return ((unsigned long long)u << 32) | (unsigned long long)(0xffffffffu - (unsigned)j);
 }
 
+// Workgroups are dispatched round-robin over the 8 XCDs (blockIdx % 8), each with its own L2.  Logical ids are handed out so
+// that one XCD gets a CONTIGUOUS range: the workgroups of one a-tile (its jsplit j-parts, which re-read the same a rows) and of
+// neighbouring a-tiles (which stream the same b rows at the same time) then share an L2 instead of each pulling its operands
+// from the Infinity Cache.  Bijective for any grid size.
+__device__ __forceinline__ int tome_xcd_logical_id() {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
 __global__ void __launch_bounds__(256, 2) k_tome_match(const float* __restrict__ ahat, const float* __restrict__ bhat,
                                                         int na, int nb, int D, int jsplit,
                                                         unsigned long long* __restrict__ best /*[na]*/) {
@@ -71,7 +81,8 @@ __global__ void __launch_bounds__(256, 2) k_tome_match(const float* __restrict__
     __shared__ float Bs[TM_K][TM_LD];     // Bs[k][j]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave & 1, wj = wave >> 1;          // wave tile: 64 (j) x 64 (i)
-    const int itile = blockIdx.x / jsplit, jpart = blockIdx.x % jsplit;
+    const int lid = tome_xcd_logical_id();
+    const int itile = lid / jsplit, jpart = lid % jsplit;
     const int i0 = itile * TM_I;
     const int jtiles = (nb + TM_J - 1) / TM_J;
     const int jt_lo = (int)((long long)jtiles * jpart / jsplit), jt_hi = (int)((long long)jtiles * (jpart + 1) / jsplit);
@@ -240,7 +251,8 @@ __global__ void __launch_bounds__(256, 2) k_tome_match16(const uint16_t* __restr
     typedef typename TomeMfma<T>::vec vec;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave & 1, wj = wave >> 1;          // wave tile: 64 (j) x 64 (i)
-    const int itile = blockIdx.x / jsplit, jpart = blockIdx.x % jsplit;
+    const int lid = tome_xcd_logical_id();
+    const int itile = lid / jsplit, jpart = lid % jsplit;
     const int i0 = itile * TM_I;
     const int jtiles = (nb + TM_J - 1) / TM_J;
     const int jt_lo = (int)((long long)jtiles * jpart / jsplit), jt_hi = (int)((long long)jtiles * (jpart + 1) / jsplit);
@@ -395,7 +407,8 @@ __global__ void __launch_bounds__(128 * WJ, 2) k_tome_match_split(const uint16_t
     typedef tome_f16x8 vec;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave & 1, wj = wave >> 1;
-    const int itile = blockIdx.x / jsplit, jpart = blockIdx.x % jsplit;
+    const int lid = tome_xcd_logical_id();
+    const int itile = lid / jsplit, jpart = lid % jsplit;
     const int i0 = itile * TI;
     const int jtiles = (nb + TJ - 1) / TJ;
     const int jt_lo = (int)((long long)jtiles * jpart / jsplit), jt_hi = (int)((long long)jtiles * (jpart + 1) / jsplit);
@@ -488,21 +501,24 @@ __global__ void __launch_bounds__(128 * WJ, 2) k_tome_match_split(const uint16_t
 }
 
 // The match on a 256 x 256 workgroup tile (8 waves of 64 (j) x 128 (i), one workgroup per CU) with the operand tiles copied
-// global -> LDS by the DMA path (global_load_lds_dwordx4: no staging registers, no ds_write pass) into two LDS buffers: the
-// copy of stage s+1 runs under the MFMAs of stage s, one barrier per stage.  A stage is 64 KB (2 x 64 KB buffers of the
-// 160 KB LDS): 32 k of both planes of both matrices for the fp16 split of fp32 inputs (NP = 2), 64 k of both matrices for
-// bf16 / fp16 inputs (NP = 1).  LDS reads per MFMA are 2/3 of the 128 x 128 kernels'.
+// global -> LDS by the DMA path (global_load_lds_dwordx4: no staging registers, no ds_write pass) into two LDS buffers.
+// A stage is 64 KB (2 x 64 KB buffers of the 160 KB LDS): 32 k of both planes of both matrices for the fp16 split of fp32
+// inputs (NP = 2), 64 k of both matrices for bf16 / fp16 inputs (NP = 1).  LDS reads per MFMA are 2/3 of the 128 x 128 kernels'.
 // An LDS-DMA instruction writes wave-linear (base + lane * 16 bytes), so rows are unpadded (64 / 128 bytes) and the bank spread
 // comes from a chunk swizzle applied to the SOURCE address: 16-byte chunk c of tile row r lives at chunk position
 // c ^ ((r / rows-per-256-bytes) & (chunks-per-row - 1)), which sends the 16 rows of a ds_read_b128 lane group to 16 different
-// 4-bank groups.
+// 4-bank groups (SQ_LDS_BANK_CONFLICT = 0).
+// Stage pipeline: every k16 step's operand fragments are read from LDS while the MFMAs of the step before run (two fragment
+// register sets), ACROSS the stage barrier -- the barrier of stage s+1 sits in front of the last step's MFMAs of stage s, so the
+// first fragments of stage s+1 are read under those MFMAs, and the DMA of stage s+2 (into the buffer everyone has just finished
+// reading) is issued there as well, two pieces after every group of 8 MFMAs.
+// NP = 2: fp32 inputs as two fp16 planes, TERMS = 4 / 3 products per k (T = f16_t).  NP = 1: 16-bit inputs of type T, one
+// product, scores rounded to T before the comparison (the reference's score tensor has the input dtype).
 typedef const __attribute__((address_space(1))) void* tome_gptr;
 typedef __attribute__((address_space(3))) void* tome_lptr;
 constexpr int TG_T = 256;                       // tile side
 constexpr int TG_BUF = 65536;                   // bytes of one stage: [matrix A, B][plane][256 rows][KS * 2 bytes]
 
-// NP = 2: fp32 inputs as two fp16 planes, TERMS = 4 / 3 products per k (T = f16_t).  NP = 1: 16-bit inputs of type T, one
-// product, scores rounded to T before the comparison (the reference's score tensor has the input dtype).
 template <int NP, int TERMS, typename T>
 __global__ void __launch_bounds__(512, 2) k_tome_match_glds(const uint16_t* __restrict__ ap, const uint16_t* __restrict__ bp,
                                                              int na, int nb, int D, int jsplit,
@@ -512,6 +528,7 @@ __global__ void __launch_bounds__(512, 2) k_tome_match_glds(const uint16_t* __re
     typedef typename TomeMfma<T>::vec vec;
     constexpr int QI = 4;
     constexpr int KS = 64 / NP;                  // k per stage
+    constexpr int NSTEP = KS / 16;               // k16 steps per stage (even)
     constexpr int RB = KS * 2;                   // bytes per tile row
     constexpr int CPR = RB / 16;                 // 16-byte chunks per row
     constexpr int RPP = 1024 / RB;               // rows per 1 KB piece
@@ -521,14 +538,16 @@ __global__ void __launch_bounds__(512, 2) k_tome_match_glds(const uint16_t* __re
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wave & 1, wj = wave >> 1;
-    const int itile = blockIdx.x / jsplit, jpart = blockIdx.x % jsplit;
+    const int lid = tome_xcd_logical_id();
+    const int itile = lid / jsplit, jpart = lid % jsplit;
     const int i0 = itile * TG_T;
     const int jtiles = (nb + TG_T - 1) / TG_T;
     const int jt_lo = (int)((long long)jtiles * jpart / jsplit), jt_hi = (int)((long long)jtiles * (jpart + 1) / jsplit);
     const int lcol = lane & 31, lhalf = lane >> 5;
+    const int NK = D / KS;                        // stages per tile product
+    const int S = (jt_hi - jt_lo) * NK;           // stages of this workgroup
+    if (S <= 0) return;
 
-    // copy plan: wave w issues pieces g = w + 8 c, c = 0..7; pieces 0..31 are A (plane-major), 32..63 B.  Piece g holds rows
-    // (g % PPM) * RPP + lane / CPR of plane (g / PPM) % NP at chunk position lane % CPR
     const int prow = lane / CPR;
     auto piece_row = [&](int g) { return (g % PPM) * RPP + prow; };
     auto src_chunk = [&](int g) { return (lane % CPR) ^ ((piece_row(g) / R256) & (CPR - 1)); };
@@ -538,81 +557,110 @@ __global__ void __launch_bounds__(512, 2) k_tome_match_glds(const uint16_t* __re
         const int g = wave + 8 * c, plane = (g / PPM) % NP;
         asrc[c] = reinterpret_cast<const char*>(ap + ((int64_t)plane * na + min(i0 + piece_row(g), na - 1)) * D + src_chunk(g) * 8);
     }
-    auto issue = [&](int buf, int j0, int k0) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int g = wave + 8 * c;
+    // piece c of stage st (tile jt_lo + st / NK, k0 = (st % NK) * KS) into buffer st & 1
+    auto issue_piece = [&](int c, int st) {
+        const int g = wave + 8 * c, buf = st & 1;
+        const int j0 = (jt_lo + st / NK) * TG_T, k0 = (st % NK) * KS;
+        if (c < 4) {
             __builtin_amdgcn_global_load_lds((tome_gptr)(asrc[c] + (int64_t)k0 * 2), (tome_lptr)(tg_smem + buf * TG_BUF + g * 1024), 16, 0, 0);
-        }
-#pragma unroll
-        for (int c = 4; c < 8; ++c) {
-            const int g = wave + 8 * c, plane = (g / PPM) % NP;
+        } else {
+            const int plane = (g / PPM) % NP;
             const char* src = reinterpret_cast<const char*>(bp + ((int64_t)plane * nb + min(j0 + piece_row(g), nb - 1)) * D + k0 + src_chunk(g) * 8);
             __builtin_amdgcn_global_load_lds((tome_gptr)src, (tome_lptr)(tg_smem + buf * TG_BUF + g * 1024), 16, 0, 0);
         }
     };
-    // fragment addresses: row * RB + (chunk ^ swizzle) * 16, chunk = ks / 8 + lhalf (the subtile bases are multiples of 32 rows)
     const int sw = (lcol / R256) & (CPR - 1);
     const int a_off = (wi * 128 + lcol) * RB, b_off = NP * PLANE + (wj * 64 + lcol) * RB;
+    struct Frag { vec b[2][NP], a[QI][NP]; };
+    auto read_frag = [&](Frag& f, int st, int step) {
+        const char* base = tg_smem + (st & 1) * TG_BUF;
+        const int coff = ((step * 2 + lhalf) ^ sw) * 16;
+#pragma unroll
+        for (int pi = 0; pi < NP; ++pi) {
+            const int pl = NP - 1 - pi;         // the l planes first: the first products need them
+#pragma unroll
+            for (int p = 0; p < 2; ++p) f.b[p][pl] = *reinterpret_cast<const vec*>(base + b_off + pl * PLANE + p * 32 * RB + coff);
+#pragma unroll
+            for (int q = 0; q < QI; ++q) f.a[q][pl] = *reinterpret_cast<const vec*>(base + a_off + pl * PLANE + q * 32 * RB + coff);
+        }
+    };
 
     float bestv[QI];
     int bestj[QI];
 #pragma unroll
     for (int q = 0; q < QI; ++q) { bestv[q] = -INFINITY; bestj[q] = 0x7fffffff; }
-    int cur = 0;
-    if (jt_lo < jt_hi) issue(0, jt_lo * TG_T, 0);
-    for (int jt = jt_lo; jt < jt_hi; ++jt) {
-        const int j0 = jt * TG_T;
-        f32x16_t acc[2][QI];
+    f32x16_t acc[2][QI];
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
-#pragma unroll
-            for (int q = 0; q < QI; ++q)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[p][q][e] = 0.f;
-        for (int k0 = 0; k0 < D; k0 += KS) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of the current stage have landed
-            __syncthreads();                                       // ... everyone's have, and the other buffer is no longer read
-            if (k0 + KS < D) issue(cur ^ 1, j0, k0 + KS);
-            else if (jt + 1 < jt_hi) issue(cur ^ 1, j0 + TG_T, 0);
-            const char* base = tg_smem + cur * TG_BUF;
-#pragma unroll
-            for (int ks = 0; ks < KS; ks += 16) {
-                const int coff = (((ks >> 3) + lhalf) ^ sw) * 16;
-                vec fb[2][NP], fa[QI][NP];      // [subtile][plane: 0 = h, 1 = l]
-#pragma unroll
-                for (int pl = 0; pl < NP; ++pl) {
-#pragma unroll
-                    for (int p = 0; p < 2; ++p)
-                        fb[p][pl] = *reinterpret_cast<const vec*>(base + b_off + pl * PLANE + p * 32 * RB + coff);
-#pragma unroll
-                    for (int q = 0; q < QI; ++q)
-                        fa[q][pl] = *reinterpret_cast<const vec*>(base + a_off + pl * PLANE + q * 32 * RB + coff);
-                }
-#pragma unroll
-                for (int term = 4 - TERMS; term < 4; ++term) {
-                    // l.l, l.h, h.l, h.h (small terms first); one plane: the only term is h.h
-                    const int pb = NP == 2 && (term == 0 || term == 1), pa = NP == 2 && (term == 0 || term == 2);
-#pragma unroll
-                    for (int p = 0; p < 2; ++p)
-#pragma unroll
-                        for (int q = 0; q < QI; ++q)
-                            acc[p][q] = TomeMfma<T>::run(fb[p][pb], fa[q][pa], acc[p][q]);
-                }
-            }
-            cur ^= 1;
-        }
-        // running max over this tile.  Split: on the scaled scores (the factor 2^-24 is applied once, at the end)
+    for (int p = 0; p < 2; ++p)
 #pragma unroll
         for (int q = 0; q < QI; ++q)
 #pragma unroll
-            for (int p = 0; p < 2; ++p)
+            for (int e = 0; e < 16; ++e) acc[p][q][e] = 0.f;
+
+    // prologue: stages 0 and 1 in flight, stage 0 landed, its first fragments read
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int j = j0 + wj * 64 + p * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
-                    const float v = NP == 1 ? tome_round<T>(acc[p][q][e]) : acc[p][q][e];
-                    if (j < nb && (v > bestv[q] || (v == bestv[q] && j < bestj[q]))) { bestv[q] = v; bestj[q] = j; }
+    for (int c = 0; c < 8; ++c) issue_piece(c, 0);
+    if (S > 1) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) issue_piece(c, 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    Frag fr[2];
+    read_frag(fr[0], 0, 0);
+
+    for (int st = 0; st < S; ++st) {
+#pragma unroll
+        for (int step = 0; step < NSTEP; ++step) {
+            Frag& cur = fr[step & 1];
+            Frag& nxt = fr[(step + 1) & 1];
+            const bool last = step == NSTEP - 1;
+            __builtin_amdgcn_sched_barrier(0);      // the MFMAs of the step before stay in front of this step's barrier / reads
+            if (!last) {
+                read_frag(nxt, st, step + 1);
+            } else {
+                // every wave has read all of stage st (the reads of this step were issued a step ago; __syncthreads waits for
+                // them); stage st+1 has landed once every wave's own pieces have
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (st + 1 < S) read_frag(nxt, st + 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);      // the reads stay in front of the MFMAs they overlap with
+            const bool feed = last && st + 2 < S;   // this step also issues the DMA of stage st+2 (into the buffer just vacated)
+#pragma unroll
+            for (int term = 4 - TERMS; term < 4; ++term) {
+                // l.l, l.h, h.l, h.h (small terms first); one plane: the only term is h.h
+                const int pb = NP == 2 && (term == 0 || term == 1), pa = NP == 2 && (term == 0 || term == 2);
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int q = 0; q < QI; ++q)
+                        acc[p][q] = TomeMfma<T>::run(cur.b[p][pb], cur.a[q][pa], acc[p][q]);
+                if (last) {
+                    const int gi = term - (4 - TERMS);
+                    if (feed) {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c)
+                            if (c * TERMS / 8 == gi) issue_piece(c, st + 2);
+                    }
                 }
+            }
+        }
+        if ((st + 1) % NK == 0) {
+            // end of a tile product: running max (split: on the scaled scores, the factor 2^-24 is applied once at the end)
+            const int j0 = (jt_lo + st / NK) * TG_T;
+#pragma unroll
+            for (int q = 0; q < QI; ++q)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int j = j0 + wj * 64 + p * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
+                        const float v = NP == 1 ? tome_round<T>(acc[p][q][e]) : acc[p][q][e];
+                        if (j < nb && (v > bestv[q] || (v == bestv[q] && j < bestj[q]))) { bestv[q] = v; bestj[q] = j; }
+                        acc[p][q][e] = 0.f;
+                    }
+        }
     }
 #pragma unroll
     for (int q = 0; q < QI; ++q) {
