@@ -7,7 +7,7 @@
 
 namespace sttm {
 
-constexpr int kMaxLevels = 5;   // deepest pyramid the fused spatial kernel supports (root .. leaf)
+constexpr int kMaxLevels = 6;   // deepest pyramid the fused spatial kernel supports (root .. leaf): root cells of up to 32 x 32 leaves
 constexpr int kWave = 64;
 
 // ---- geometry (closed form of quadtree_spatial_merger.py:155-271 of the reference) -----------------

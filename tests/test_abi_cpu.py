@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
 
 
 @pytest.mark.parametrize("H,W", [(14, 14), (27, 27), (20, 36), (18, 26), (13, 24), (16, 22), (10, 30), (7, 7),
-                                  (4, 4), (3, 5), (24, 13), (2, 9), (9, 2), (36, 36)])
+                                  (4, 4), (3, 5), (24, 13), (2, 9), (9, 2), (36, 36), (36, 64), (100, 128), (70, 200)])
 def test_num_levels_matches_oracle_geometry(H, W):
     from oracle import sttm_oracle as O
     lib = _lib.load()
@@ -38,7 +38,7 @@ def test_num_levels_matches_oracle_geometry(H, W):
         except IndexError:
             assert got == _lib.ERR_INDEX
             continue
-        if exp > 5:
+        if exp > 6:                                   # kMaxLevels: root cells of up to 32 x 32 leaves
             assert got == _lib.ERR_UNSUPPORTED
         else:
             assert got == exp, (H, W, root)

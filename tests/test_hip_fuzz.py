@@ -49,7 +49,7 @@ def test_fuzz_against_oracle(case):
         return
     try:
         out = get_quadtree_features(x.to(dev), thr, tthr, root, weighted, slow_ver=slow)
-    except NotImplementedError as e:             # documented device limits (tree deeper than 5 levels, ...)
+    except NotImplementedError as e:             # documented device limits (trees deeper than 6 levels: not reachable with W <= 40)
         pytest.skip(str(e))
     f, n, t = (o.cpu() for o in out)
     ef, en, et = exp

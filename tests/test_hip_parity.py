@@ -111,6 +111,13 @@ ORACLE_CASES = [
     (180, 1024, 14, 14, 33, torch.float32, 0.94, 0.82, 1, False),  # C5: MLVU 180 frames (run_vidqa.sh:89)
     (180, 1024, 14, 14, 34, torch.bfloat16, 0.94, 0.82, 1, False),
     (4200, 16, 14, 14, 35, torch.float32, 0.85, 0.55, 1, False),   # 67 200 label slots per column: past the 16-bit slot ids of round 1
+    # 6-level trees (three levels above the register blocks): root cells of up to 32 x 32 leaves
+    (3, 256, 36, 64, 36, torch.float32, 0.85, 0.55, 0, False),
+    (3, 128, 40, 40, 37, torch.bfloat16, 0.80, 0.50, 0, False),
+    (2, 64, 64, 64, 38, torch.float32, 0.90, 0.60, 0, True),
+    (2, 1024, 33, 47, 39, torch.float32, 0.75, 0.50, 0, False),     # odd sides at several levels (alias cells), smooth enough to stop high up
+    (2, 2048, 36, 64, 40, torch.float16, 0.85, 0.55, 0, False),     # 32-byte packs
+    (2, 96, 128, 100, 41, torch.float32, 0.85, 0.55, 1, False),     # 6 levels through root_level 1 on a 128-wide grid
 ]
 
 
@@ -126,8 +133,27 @@ def test_against_oracle(case):
     _check(out, exp, FP32_TOL if dtype == torch.float32 else BF16_TOL, str(case[:5]))
 
 
+@pytest.mark.parametrize("pe_weighted", [False, True])
+def test_position_embeddings_on_a_six_level_tree(pe_weighted):
+    """`pos_embs` pooling (quadtree_builder.py:75-81) over the nodes of a 6-level tree: root cells of up to 32 x 32 leaves."""
+    from oracle import sttm_oracle as O
+    from sttm_amd import get_quadtree_features
+    from sttm_amd.synth import synth_video
+    x = synth_video(2, 64, 40, 40, seed=90, c=0.1, p_static=0.8)
+    pe = (synth_video(2, 32, 40, 40, seed=91), synth_video(2, 32, 40, 40, seed=92))
+    exp = O.get_quadtree_features(x, 0.80, 0.50, 0, False, pos_embs=pe, pos_emb_weighted_avg=pe_weighted)
+    out = get_quadtree_features(x.to(_dev()), 0.80, 0.50, 0, False, pos_embs=tuple(p.to(_dev()) for p in pe),
+                                pos_emb_weighted_avg=pe_weighted)
+    _check(out[:3], exp[:3], FP32_TOL, "6-level pos_embs")
+    assert int((exp[1] > 256).sum()) > 0, "the case should contain nodes above the block level"
+    for got, want in zip(out[3], exp[3]):
+        assert got.shape == want.shape
+        assert float((got.cpu() - want).abs().max()) <= FP32_TOL
+
+
 @pytest.mark.parametrize("T,C,H,W,hd,dtype,root", [(6, 512, 14, 14, 64, torch.float32, 1), (4, 3584, 14, 14, 128, torch.bfloat16, 1),
-                                                       (4, 256, 20, 36, 32, torch.float32, 1), (3, 256, 27, 27, 64, torch.float32, 0)])
+                                                       (4, 256, 20, 36, 32, torch.float32, 1), (3, 256, 27, 27, 64, torch.float32, 0),
+                                                       (2, 256, 40, 36, 64, torch.float32, 0)])
 def test_per_head_similarity_against_oracle(T, C, H, W, hd, dtype, root):
     """sim_per_head: head_dim = the decoder's head size (quadtree_attn_monkey_patch.py:99)."""
     from oracle import sttm_oracle as O
