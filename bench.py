@@ -254,6 +254,19 @@ def main():
                          "note": "whole get_tome_features call (normalise + match + sort + merge) over the match's ALGORITHMIC fp32 flops; "
                                  "peak = 2500 TFLOP/s fp16 dense MFMA / 4 product terms per fp32 score; x_fp32_mfma_peak = the same rate "
                                  "over the 157.3 TFLOP/s fp32-input MFMA peak (round 1's kernel)"}}
+        # the same clips as bfloat16 hidden states (what the reference's hook hands over in production): one bf16 MFMA per product
+        xb = [pool[v % P].to(torch.bfloat16) for v in range(min(P, 4))]
+        get_tome_features(xb[0], 0.5, "video")
+
+        def run_tome_bf16():
+            for v in range(NT):
+                get_tome_features(xb[v % len(xb)], 0.5, "video")
+        tome16_vps = timed(run_tome_bf16, NT)
+        ext["tome_extension"]["bf16_inputs"] = {
+            "value": round(tome16_vps, 2), "unit": "videos/s",
+            "roofline": {"bound": "mfma", "achieved": round(flops * tome16_vps / world / 1e12, 2), "peak": MFMA_F16_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(flops * tome16_vps / world / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)}}
+        del xb
         log(f"tome extension: {tome_vps:.1f} videos/s = {ext['tome_extension']['roofline']['achieved']} TFLOP/s")
 
     # ---- roofline leg: per-kernel HIP events recorded by the library on the launch stream, a bounded number of calls ----
