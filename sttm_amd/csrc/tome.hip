@@ -198,28 +198,57 @@ template <> __device__ __forceinline__ void tome_st<f16_t>(void* p, int64_t i, f
 
 // unit rows in the input dtype: m = mean over heads (fp32 sum, rounded), |m| = sqrt(fp32 sum of squares) rounded,
 // m / |m| rounded; rows padded with zeros to the 32-wide k tile.  One wave per token row.
-template <typename T>
+// VEC = 8: one head, D % 8 == 0, 16-byte aligned rows (the production shape): one 16-byte load per lane and chunk, the row stays
+// in registers between the two passes (D <= 4096).  VEC = 1: any shape.
+template <typename T, int VEC>
 __global__ void __launch_bounds__(256) k_tome_normalize16(const void* __restrict__ x, int n, int C, int n_head, int D, int Dp,
                                                           uint16_t* __restrict__ ahat, uint16_t* __restrict__ bhat) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     for (int row = blockIdx.x * nwave + wave; row < n; row += gridDim.x * nwave) {
         uint16_t* out = ((row & 1) ? bhat : ahat) + (int64_t)(row >> 1) * Dp;
-        float ss = 0.f;
-        for (int d = lane; d < D; d += 64) {
-            float m;
-            if (n_head == 1) {
-                m = tome_ld<T>(x, (int64_t)row * C + d);
-            } else {
-                float s = 0.f;
-                for (int h = 0; h < n_head; ++h) s += tome_ld<T>(x, (int64_t)row * C + h * D + d);
-                m = tome_round<T>(s / (float)n_head);
+        if constexpr (VEC == 8) {
+            constexpr int MAXCH = 8;                     // chunks of 512 elements: D <= 4096
+            Pack<T, 8> v[MAXCH];
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < MAXCH; ++i) {
+                const int d = (i * 64 + lane) * 8;
+                if (d < D) {
+                    v[i] = load_pack<T, 8>(x, (int64_t)row * C + d);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float m = v[i].get(e); ss = fmaf(m, m, ss); }
+                }
             }
-            tome_st<T>(out, d, m);
-            ss = fmaf(m, m, ss);
+            ss = wave_sum(ss);
+            const float nrm = tome_round<T>(sqrtf(ss));
+#pragma unroll
+            for (int i = 0; i < MAXCH; ++i) {
+                const int d = (i * 64 + lane) * 8;
+                if (d < D) {
+                    Pack<T, 8> o;
+                    const Pack<T, 8> in = v[i];
+                    pack_fill<T, 8>(o, [&](int e) { return in.get(e) / nrm; });
+                    store_pack<T, 8>(out, d, o);
+                }
+            }
+        } else {
+            float ss = 0.f;
+            for (int d = lane; d < D; d += 64) {
+                float m;
+                if (n_head == 1) {
+                    m = tome_ld<T>(x, (int64_t)row * C + d);
+                } else {
+                    float s = 0.f;
+                    for (int h = 0; h < n_head; ++h) s += tome_ld<T>(x, (int64_t)row * C + h * D + d);
+                    m = tome_round<T>(s / (float)n_head);
+                }
+                tome_st<T>(out, d, m);
+                ss = fmaf(m, m, ss);
+            }
+            ss = wave_sum(ss);
+            const float nrm = tome_round<T>(sqrtf(ss));
+            for (int d = lane; d < D; d += 64) tome_st<T>(out, d, tome_ld<T>(out, d) / nrm);
         }
-        ss = wave_sum(ss);
-        const float nrm = tome_round<T>(sqrtf(ss));
-        for (int d = lane; d < D; d += 64) tome_st<T>(out, d, tome_ld<T>(out, d) / nrm);
         for (int d = D + lane; d < Dp; d += 64) out[d] = 0;
     }
 }
@@ -690,31 +719,30 @@ __global__ void k_tome_count(const int* __restrict__ order, const int* __restric
 }
 
 __global__ void __launch_bounds__(1024) k_tome_scan(const int* __restrict__ cnt, int nb, int* __restrict__ off) {
-    // single workgroup exclusive scan (nb is a few 10^4 at most)
+    // single workgroup exclusive scan (nb is a few 10^4 at most): every thread owns a contiguous run of elements, the
+    // workgroup scans the 1024 run totals once, and every thread writes the prefixes of its run
     __shared__ int wsum[16];
-    __shared__ int carry;
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = nt >> 6;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < nb; base += nt) {
-        const int i = base + tid;
-        const int v = i < nb ? cnt[i] : 0;
-        int inc = v;
+    const int per = (nb + nt - 1) / nt;
+    const int lo = min(tid * per, nb), hi = min(lo + per, nb);
+    int total = 0;
+    for (int i = lo; i < hi; ++i) total += cnt[i];
+    int inc = total;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int o = __shfl_up(inc, d, 64);
-            if (lane >= d) inc += o;
-        }
-        if (lane == 63) wsum[wave] = inc;
-        __syncthreads();
-        int pre = carry;
-        for (int w = 0; w < wave; ++w) pre += wsum[w];
-        if (i < nb) off[i] = pre + inc - v;
-        __syncthreads();
-        if (tid == nt - 1) carry = pre + inc;
-        __syncthreads();
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
     }
-    if (tid == 0) off[nb] = carry;
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int pre = inc - total;
+    for (int w = 0; w < wave; ++w) pre += wsum[w];
+    for (int i = lo; i < hi; ++i) { off[i] = pre; pre += cnt[i]; }
+    if (tid == nt - 1) {
+        int all = 0;
+        for (int w = 0; w < nwave; ++w) all += wsum[w];
+        off[nb] = all;
+    }
 }
 
 __global__ void k_tome_fill(const int* __restrict__ order, const int* __restrict__ node_idx, int r, const int* __restrict__ off,
@@ -964,7 +992,10 @@ int sttm_tome_step(const void* x_, const float* size, const int64_t* idx, int n,
         const int js = pick_jsplit(it, TG_T, 1);
 #define STTM_TOME_16(TT)                                                                                                            \
         do {                                                                                                                        \
-            hipLaunchKernelGGL(k_tome_normalize16<TT>, dim3(ngrid), dim3(256), 0, stream, x_, n, C, n_head, p.D, p.Dp, ap, bp);       \
+            if (n_head == 1 && C % 8 == 0 && C <= 4096 && reinterpret_cast<uintptr_t>(x_) % 16 == 0)                              \
+                hipLaunchKernelGGL((k_tome_normalize16<TT, 8>), dim3(ngrid), dim3(256), 0, stream, x_, n, C, n_head, p.D, p.Dp, ap, bp); \
+            else                                                                                                                    \
+                hipLaunchKernelGGL((k_tome_normalize16<TT, 1>), dim3(ngrid), dim3(256), 0, stream, x_, n, C, n_head, p.D, p.Dp, ap, bp); \
             if (big) hipLaunchKernelGGL((k_tome_match_glds<1, 1, TT>), dim3(it * js), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best); \
             else hipLaunchKernelGGL(k_tome_match16<TT>, dim3(itiles * jsplit), dim3(256), 0, stream, ap, bp, p.na, p.nb, p.Dp, jsplit, best); \
         } while (0)
