@@ -4,11 +4,12 @@
 //                  and, in the LAST pair workgroup of every root-cell column to finish, that column's label stage
 //   k_slow_filter  slow_ver: per frame pair, similarity sort + adjacent-duplicate removal                (:75-121)
 //   column label stage  label propagation per root-cell column                                          (:223-269)
-//                  probe -> grid barrier -> exact replay -> group sizes -> per-frame survivor counts -> arrival word (N'
-//                  to the host).  Runs inside k_pairs (folded), or as k_col_labels<FUSED> (one launch) /
+//                  probe -> grid barrier -> exact replay -> group sizes -> per-frame survivor counts -> N' word.
+//                  Runs inside k_pairs (folded), or as k_col_labels<FUSED> (one launch) /
 //                  <PROBE> + <FINAL> (two launches, no co-residency assumption)
 //   k_group_mean   ranks the survivors of its frame, finds each survivor's members by scanning its column's labels,
-//                  per-survivor ascending-order accumulation and mean                                     (:123-171)
+//                  per-survivor ascending-order accumulation and mean                                     (:123-171);
+//                  its first workgroup publishes N' to the host
 //
 // All of them address nodes by their ORIGIN ROW  t*H*W + y1*W + x1  in the scratch matrix S written by the
 // spatial kernel (1x1 nodes stay in x).  Origin rows are ordered exactly like the reference's sorted node
@@ -224,7 +225,7 @@ __device__ __forceinline__ void column_iteration(int* rep, int* rep2, const int*
 
 // Grid-wide barrier among the column workgroups (all resident: see labels_can_fuse / labels_can_fold).  The spin is
 // bounded: on a timeout false is returned -- the caller skips the rest of its column instead of continuing with partial data
-// and reports the overflow through the arrival word (the Python wrapper then fails loudly).
+// and reports the overflow through the N' word (the Python wrapper then fails loudly).
 __device__ __forceinline__ bool grid_barrier(int32_t* counter, int target, int* ok_lds) {
     // Everything that crosses this barrier is written with agent-scope (write-through, sc1) stores or atomics and read
     // with agent-scope loads, so no release/acquire cache maintenance is needed: every wave drains its stores, one lane
@@ -245,7 +246,8 @@ __device__ __forceinline__ bool grid_barrier(int32_t* counter, int target, int* 
     return *ok_lds != 0;
 }
 
-// N' (and the overflow flag) go straight into pinned host memory: the caller learns N' while k_group_mean still runs.
+// N' (and the overflow flag) go straight into pinned host memory (first workgroup of k_group_mean): the caller learns N'
+// while that kernel still runs.
 // The bookkeeping slots (nodes, candidates, edges, iterations) stay device-side: they are diagnostics, added with
 // fire-and-forget atomics that nobody waits for, and are complete once the stream has drained.
 __device__ __forceinline__ void publish_counts(const TemporalArgs& a, int n_out, int overflow) {
@@ -266,7 +268,7 @@ __device__ __forceinline__ void publish_counts(const TemporalArgs& a, int n_out,
 //        COL_FINAL : read every column's history, replay exactly K iterations, write the results
 //        COL_FUSED : probe -> grid barrier -> (replay only if K is smaller than this column's own count) -> results
 // Results: lab_row / gcnt of the column's active nodes (the spatial kernel wrote the singleton defaults), the column's
-// survivors added to frame_cnt[t], bookkeeping counters, and -- by the last column to finish -- N' to the host.
+// survivors added to frame_cnt[t], bookkeeping counters, and the column's share of N' (+ overflow events) in one 64-bit word.
 template <bool GMEM, int MODE>
 __device__ __forceinline__ bool column_labels(const TemporalArgs& a, int r, const Column& col, const ColArrays& arr, ColShared* sh) {
     const int R = a.R;
@@ -466,10 +468,11 @@ __device__ __forceinline__ bool column_labels(const TemporalArgs& a, int r, cons
         STTM_LBL_TICK(7);
     }
     // ---- N' and the bookkeeping counters.  The per-wave partials meet in LDS; thread 0 adds (survivors << 24 | 1) -- plus
-    // this column's overflow events in the top byte -- to ONE 64-bit word (R < 2^24 columns, N' < 2^31): the add that
-    // completes the arrival count also returns the complete N', so the last column publishes it to the host with no second
-    // grid barrier and no drain of anybody's stores (their consumer is the next kernel).  The diagnostic counters are
-    // fire-and-forget atomics.
+    // this column's overflow events in the top byte -- to ONE 64-bit word (R < 2^24 columns, N' < 2^31) with a fire-and-forget
+    // atomic, like the diagnostic counters: nobody in this kernel waits for a returned value or drains stores (round 2 had the
+    // last column to arrive publish N' itself: a returning atomic plus three host stores at the very end of the 16-workgroup
+    // critical path, 1.2 us of kernel time).  The word is complete at the kernel boundary; the first workgroup of the group-mean
+    // kernel forwards it to the host.
     int cand = temporal ? cand_pre : 0;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -485,16 +488,12 @@ __device__ __forceinline__ bool column_labels(const TemporalArgs& a, int r, cons
             for (int k = 0; k < 4; ++k) tot[k] += sh->part[k][w];
         unsigned long long* word = reinterpret_cast<unsigned long long*>(a.bar + 2);
         const unsigned long long mine = ((unsigned long long)(ovf > 127 ? 127 : ovf) << 56) | ((unsigned long long)(unsigned)tot[2] << 24) | 1ull;
-        const unsigned long long old = __hip_atomic_fetch_add(word, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        (void)__hip_atomic_fetch_add(word, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tot[0]) atomicAdd(a.counts + STTM_CNT_NODES, tot[0]);
         if (tot[1]) atomicAdd(a.counts + STTM_CNT_LEAFNODES, tot[1]);
         if (tot[3]) atomicAdd(a.counts + STTM_CNT_CANDIDATES, tot[3]);
         if (E) atomicAdd(a.counts + STTM_CNT_EDGES, E);
         if (r == 0) st_agent(a.counts + STTM_CNT_ITERS, K);
-        if ((int)(old & 0xffffffull) == R - 1) {
-            const unsigned long long all = old + mine;
-            publish_counts(a, (int)((all >> 24) & 0xffffffffull), (int)(all >> 56));
-        }
     }
     STTM_LBL_TICK(8);
     return true;
@@ -919,6 +918,11 @@ __global__ void __launch_bounds__(256, TypeInfo<T>::lowp ? 6 : 8) k_group_mean(c
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     const int S = a.gm_split, t = blockIdx.x / S, s = blockIdx.x - t * S;
     const int HW = a.H * a.W;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.bar) {     // (a.bar is null when this kernel only re-merges another tensor: sttm_quadtree_apply)
+        // the label stage left (overflow << 56 | N' << 24 | columns) in one word; complete at this kernel boundary
+        const unsigned long long all = __hip_atomic_load(reinterpret_cast<unsigned long long*>(a.bar + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        publish_counts(a, (int)((all >> 24) & 0xffffffffull), (int)(all >> 56));
+    }
     const int stride = S * nwave, me = s * nwave + wave;
     // output rows before this frame: every wave sums frame_cnt[0..t) for itself (no LDS, no workgroup barrier)
     int row0 = 0;

@@ -84,8 +84,8 @@ def _scratch(dev, stream, nbytes, rows):
 
 
 def _wait(lib, host_row, seq, stream, counts_row):
-    # Output sizes are data dependent, so the host must learn N' -- but only N': the label stage publishes the counts into
-    # pinned memory and we wait on that, returning while the feature gather is still running.
+    # Output sizes are data dependent, so the host must learn N' -- but only N': the first workgroup of the group-mean kernel
+    # publishes the counts into pinned memory and we wait on that, returning while the feature gather is still running.
     if lib.sttm_wait_counts(host_row.data_ptr(), seq, 2_000_000) != 0:
         host_row.copy_(counts_row, non_blocking=True)  # fallback: classic D2H + stream sync
         stream.synchronize()
