@@ -60,7 +60,8 @@ struct SpatialArgs {
     uint32_t* cgeo;           // [H*W] per leaf position: its root cell's first leaf row / column and extent, Y1 | X1<<8 | aw<<16 | ah<<24
     int32_t* counts;          // STTM_CNT_* slots (zeroed here, filled by the later kernels)
     int32_t* frame_cnt;       // [T] zeroed here for the label stage
-    int32_t* bar;             // [4] zeroed here: [0] grid-barrier counter of the label stage, [2..3] the 64-bit arrival/total word
+    int32_t* bar;             // [8] zeroed here: [1] sticky overflow flag of the pair kernel, [2..3] the 64-bit N' word, [4..5] the label stage's
+                              // 64-bit grid-barrier word (arrivals + per-iteration idempotency counts)
     int32_t* col_arrive;      // [R] zeroed here: pair workgroups of a column that have published their edges
 #ifdef STTM_DEV
     DevHooks dev;
@@ -107,7 +108,7 @@ struct TemporalArgs {
     unsigned long long* col_mask;   // [R] per-column idempotency history (bit k = idempotent after iteration k+1)
     int32_t* col_arrive;      // [R] arrivals of a column's pair workgroups (zeroed by the spatial kernel)
     int32_t* frame_cnt;       // [T] survivors per frame (zeroed by the spatial kernel)
-    int32_t* bar;             // [4] grid-barrier counter + arrival word (zeroed by the spatial kernel)
+    int32_t* bar;             // [8] overflow flag, N' word, grid-barrier word (zeroed by the spatial kernel)
     int no_fuse, want_fold;   // options: two-launch label path / label stage inside the pair kernel (opt-in)
     int fold_kb;              // LDS budget (KB) of a pair workgroup when the label stage is folded in
     int fold_labels;          // the last pair workgroup of a column to arrive runs that column's label stage

@@ -177,7 +177,7 @@ struct ColShared {   // small per-workgroup scratch, carved from dynamic LDS
     int ecount;
     int last;        // k_pairs: this workgroup is the column's last arriver
     int ok;          // grid barrier passed
-    int pad;
+    int kfast;       // K as read off the barrier word (0: not decided there)
 };
 
 template <bool GMEM> __device__ __forceinline__ void edge_get(const int* edges, int e, int& d, int& s) {
@@ -223,24 +223,43 @@ __device__ __forceinline__ void column_iteration(int* rep, int* rep2, const int*
     col_sync<GMEM>();
 }
 
-// Grid-wide barrier among the column workgroups (all resident: see labels_can_fuse / labels_can_fold).  The spin is
-// bounded: on a timeout false is returned -- the caller skips the rest of its column instead of continuing with partial data
-// and reports the overflow through the N' word (the Python wrapper then fails loudly).
-__device__ __forceinline__ bool grid_barrier(int32_t* counter, int target, int* ok_lds) {
+// Grid-wide barrier among the column workgroups (all resident: see labels_can_fuse / labels_can_fold) that also carries the
+// iteration agreement.  The barrier word holds six 10-bit fields: [0] arrivals, [1 + k] columns whose labels are idempotent
+// after iteration k + 1 (k < 5).  Every column adds its whole contribution with ONE atomic, so the poll that sees R arrivals
+// sees complete counts: K = the first k + 1 whose field equals R -- without the separate read of every column's history
+// (*k_lds = 0 when no field qualifies or R > 1023: the caller then reads the histories).  The spin is bounded: on a timeout
+// false is returned -- the caller skips the rest of its column instead of continuing with partial data and reports the
+// overflow through the N' word (the Python wrapper then fails loudly).
+__device__ __forceinline__ bool grid_barrier(unsigned long long* word, int target, unsigned long long history, int* ok_lds, int* k_lds) {
     // Everything that crosses this barrier is written with agent-scope (write-through, sc1) stores or atomics and read
     // with agent-scope loads, so no release/acquire cache maintenance is needed: every wave drains its stores, one lane
-    // arrives and polls the counter.
+    // arrives and polls the word.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool packed = target <= 1023;
+        unsigned long long mine = 1ull;
+        if (packed) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) mine += ((history >> k) & 1ull) << (10 * (k + 1));
+        }
+        __hip_atomic_fetch_add(word, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const long long t0 = wall_clock64();                       // 100 MHz
         int ok = 1;
-        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        unsigned long long w;
+        const unsigned long long arrivals_mask = packed ? 0x3ffull : ~0ull;
+        while (((w = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & arrivals_mask) < (unsigned long long)target) {
             __builtin_amdgcn_s_sleep(1);
             if (wall_clock64() - t0 > 200000000ll) { ok = 0; break; }    // 2 s
         }
+        int kf = 0;
+        if (ok && packed) {
+#pragma unroll
+            for (int k = 4; k >= 0; --k)
+                if ((int)((w >> (10 * (k + 1))) & 0x3ffull) == target) kf = k + 1;
+        }
         *ok_lds = ok;
+        *k_lds = kf;
     }
     __syncthreads();
     return *ok_lds != 0;
@@ -383,6 +402,7 @@ __device__ __forceinline__ bool column_labels(const TemporalArgs& a, int r, cons
     }
 
     int probe_iters = 0;
+    unsigned long long history = ~0ull;          // this column's idempotency history (all ones: a column without edges never moves)
     if (MODE != COL_FINAL && temporal) {
         // ---- PROBE: iterate to the fixed point, remember after which iterations the labels were idempotent --
         unsigned long long mask = 0ull;
@@ -399,8 +419,9 @@ __device__ __forceinline__ bool column_labels(const TemporalArgs& a, int r, cons
             if (!changed) break;                 // fixed point: stable => idempotent from here on
             if (it >= kMaxProbeIters) { overflow = true; break; }
         }
+        mask |= ~0ull << (it - 1);               // the labels no longer move: every later iteration is idempotent
+        history = mask;
         if (tid == 0) {
-            mask |= ~0ull << (it - 1);           // the labels no longer move: every later iteration is idempotent
             __hip_atomic_store(a.col_mask + r, mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (overflow) ovf += 1;
         }
@@ -410,7 +431,7 @@ __device__ __forceinline__ bool column_labels(const TemporalArgs& a, int r, cons
     STTM_LBL_TICK(3);
     bool alive = true;
     if constexpr (MODE == COL_FUSED) {
-        alive = grid_barrier(a.bar + 0, R, &sh->ok);
+        alive = grid_barrier(reinterpret_cast<unsigned long long*>(a.bar + 4), R, history, &sh->ok, &sh->kfast);
         if (!alive) ovf += 1;
     }
     STTM_LBL_TICK(4);
@@ -418,15 +439,20 @@ __device__ __forceinline__ bool column_labels(const TemporalArgs& a, int r, cons
     if (alive) {
         // ---- FINAL: K = first iteration after which EVERY column is idempotent; labels after exactly K iterations --
         if (temporal) {
-            unsigned long long m = ~0ull;
-            for (int c = tid; c < R; c += nt) m &= __hip_atomic_load(a.col_mask + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int kfast = MODE == COL_FUSED ? sh->kfast : 0;     // the barrier word usually decides K
+            if (kfast > 0) {
+                K = kfast;
+            } else {
+                unsigned long long m = ~0ull;
+                for (int c = tid; c < R; c += nt) m &= __hip_atomic_load(a.col_mask + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) m &= __shfl_xor(m, d, 64);
-            if (lane == 0) sh->wmask[wave] = m;
-            col_sync<GMEM>();
-            unsigned long long all = ~0ull;
-            for (int w = 0; w < nwave; ++w) all &= sh->wmask[w];
-            K = all ? __ffsll((long long)all) : kMaxProbeIters;      // lowest set bit index + 1
+                for (int d = 32; d >= 1; d >>= 1) m &= __shfl_xor(m, d, 64);
+                if (lane == 0) sh->wmask[wave] = m;
+                col_sync<GMEM>();
+                unsigned long long all = ~0ull;
+                for (int w = 0; w < nwave; ++w) all &= sh->wmask[w];
+                K = all ? __ffsll((long long)all) : kMaxProbeIters;      // lowest set bit index + 1
+            }
             // fused: this column already sits at its fixed point, reached after probe_iters - 1 iterations; that is the
             // answer whenever K is at least that.  Otherwise (and in the two-kernel path) replay exactly K iterations.
             if (MODE == COL_FINAL || K < probe_iters - 1) {
