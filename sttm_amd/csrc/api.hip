@@ -55,6 +55,18 @@ sttm::DevHooks g_dev = {};
 
 inline int ceil_half(int v) { return (v + 1) / 2; }
 
+// The spatial kernels read token rows through a buffer descriptor per frame with 32-bit row offsets (quadtree_spatial.inc):
+// a frame must span < 2 GiB and the strides must not be negative (any channels-last view of a real tensor qualifies).
+int check_frame_addressing(int H, int W, int C, int eb, int64_t stride_h, int64_t stride_w, int64_t stride_t) {
+    if (stride_t < 0 || stride_h < 0 || stride_w < 0)
+        return fail(STTM_ERR_UNSUPPORTED, "negative strides are not supported (make the input contiguous in [T, H, W, C])");
+    const long double ext = ((long double)(H - 1) * stride_h + (long double)(W - 1) * stride_w + C) * eb;
+    if (ext >= 2147483648.0L)
+        return fail(STTM_ERR_UNSUPPORTED, "one frame of the input view spans %.1f GiB; the spatial kernel addresses a frame with 32-bit offsets "
+                    "(make the input contiguous in [T, H, W, C])", (double)(ext / 1073741824.0L));
+    return STTM_OK;
+}
+
 // Level list of quadtree_builder.py:101-117: halve (ceil) until EITHER side is 2, then build pyramid levels
 // until the WIDTH equals the width of entry `root_level` (negative indices count from the fine end).
 int build_dims(int H, int W, int root_level, sttm::LevelDims* out) {
@@ -334,6 +346,7 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
     }
     const void* x_align = reinterpret_cast<const void*>(all_bits);      // the least aligned of the inputs decides the pack width
     int nt = 0;
+    if (int rc = check_frame_addressing(H, W, C, (int)elem_bytes(dtype), stride_h, stride_w, stride_t)) return rc;
     const int vec = pick_vec(C, dtype, x_align, stride_t, stride_h, stride_w, &nt, head_dim == 0);
     if (!vec) return fail(STTM_ERR_UNSUPPORTED, "C=%d with this alignment does not fit one workgroup (need C/vec <= 1024 lanes)", C);
 
@@ -550,6 +563,7 @@ int sttm_quadtree_apply(const void* v, int64_t stride_t, int64_t stride_c, int64
             return fail(STTM_ERR_PARITY, "position-embedding pooling needs equal parities at every pooled level; level %dx%d is mixed",
                         p.dims.h[l], p.dims.w[l]);
     int nt = 0;
+    if (int rc = check_frame_addressing(H, W, Cv, (int)elem_bytes(dtype_v), stride_h, stride_w, stride_t)) return rc;
     const int vec = pick_vec(Cv, dtype_v, v, stride_t, stride_h, stride_w, &nt);
     if (!vec) return fail(STTM_ERR_UNSUPPORTED, "channel count / alignment of the side tensor is not supported");
     Buffers b;

@@ -56,7 +56,11 @@ def _counts_host(device, stream_handle, rows=1):
 def _channels_last(x):
     """The production layout is a channels-last VIEW (stride_c == 1); anything else gets one transposing copy (enqueued on the
     current stream, before the kernels that read it)."""
-    if x.stride(1) != 1 or (x.data_ptr() % 16) != 0:
+    T, C, H, W = x.shape
+    # the spatial kernel addresses one frame with 32-bit byte offsets (csrc/quadtree_spatial.inc): a view whose frame spans
+    # 2 GiB or more (exotic strides) is copied too
+    frame_span = ((H - 1) * x.stride(2) + (W - 1) * x.stride(3) + C) * x.element_size()
+    if x.stride(1) != 1 or (x.data_ptr() % 16) != 0 or frame_span >= 2 ** 31:
         x = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
     return x
 
