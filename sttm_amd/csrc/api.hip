@@ -349,6 +349,10 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
     if (int rc = check_frame_addressing(H, W, C, (int)elem_bytes(dtype), stride_h, stride_w, stride_t)) return rc;
     const int vec = pick_vec(C, dtype, x_align, stride_t, stride_h, stride_w, &nt, head_dim == 0);
     if (!vec) return fail(STTM_ERR_UNSUPPORTED, "C=%d with this alignment does not fit one workgroup (need C/vec <= 1024 lanes)", C);
+    // a 6-level tree keeps 2735 partial statistics per wave in LDS (10.7 KB): at most 12 waves fit next to the other tables
+    if (p.dims.n_level >= 6 && nt > 768)
+        return fail(STTM_ERR_UNSUPPORTED, "a %d-level tree with %d lanes per token row does not fit the LDS (6-level trees: <= 768 lanes, "
+                    "i.e. fp32 C <= 3072, 16-bit C <= 6144)", p.dims.n_level, nt);
 
     int n_head = 0, head_lanes = 0;
     if (head_dim > 0) {

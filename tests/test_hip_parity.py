@@ -133,6 +133,20 @@ def test_against_oracle(case):
     _check(out, exp, FP32_TOL if dtype == torch.float32 else BF16_TOL, str(case[:5]))
 
 
+def test_six_level_tree_row_width_limit():
+    """6-level trees keep 10.7 KB of partial statistics per wave in LDS: rows of up to 768 lanes (12 waves) work, wider ones are
+    refused loudly (NotImplementedError), never launched."""
+    from oracle import sttm_oracle as O
+    from sttm_amd import get_quadtree_features
+    from sttm_amd.synth import synth_video
+    x = synth_video(1, 3072, 36, 40, seed=95)                  # 768 lanes of 4 floats
+    exp = O.get_quadtree_features(x, 0.85, -1.0, 0, False)
+    out = get_quadtree_features(x.to(_dev()), 0.85, -1.0, 0, False)
+    _check(out, exp, FP32_TOL, "6 levels, 768 lanes")
+    with pytest.raises(NotImplementedError, match="LDS"):
+        get_quadtree_features(synth_video(1, 4096, 36, 40, seed=96).to(_dev()), 0.85, -1.0, 0, False)
+
+
 @pytest.mark.parametrize("pe_weighted", [False, True])
 def test_position_embeddings_on_a_six_level_tree(pe_weighted):
     """`pos_embs` pooling (quadtree_builder.py:75-81) over the nodes of a 6-level tree: root cells of up to 32 x 32 leaves."""
