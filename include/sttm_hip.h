@@ -52,7 +52,10 @@ extern "C" {
 #define STTM_CNT_EDGES 2      /* L' : pairs kept by the cosine filter                                */
 #define STTM_CNT_OUT 3        /* N' : merged tokens written to the outputs                           */
 #define STTM_CNT_ITERS 4      /* label-propagation iterations                                        */
-#define STTM_CNT_OVERFLOW 5   /* != 0 : an internal list overflowed (never expected; outputs invalid)*/
+#define STTM_CNT_OVERFLOW 5   /* != 0 : outputs invalid.  Bit 6 (STTM_OVF_BARRIER_TIMEOUT): the in-kernel grid barrier of the fused
+                                 label stage timed out (other streams held the CUs) -- repeat the call with sttm_configure("no_fuse", 1);
+                                 lower bits: an internal list overflowed (never expected) */
+#define STTM_OVF_BARRIER_TIMEOUT 64
 #define STTM_CNT_LEAFNODES 6  /* spatial-stage nodes that are single 1x1 tokens (their rows are never copied) */
 #define STTM_CNT_SLOTS 8
 

@@ -14,6 +14,7 @@ STTM_F32, STTM_BF16, STTM_F16 = 0, 1, 2
 ERR_ARG, ERR_UNSUPPORTED, ERR_LAUNCH, ERR_INDEX, ERR_PARITY, ERR_TIMEOUT = -1, -2, -3, -4, -5, -6
 ABI_VERSION = 4            # STTM_ABI_VERSION of include/sttm_hip.h this binding was written for
 CNT_NODES, CNT_CANDIDATES, CNT_EDGES, CNT_OUT, CNT_ITERS, CNT_OVERFLOW, CNT_LEAFNODES, CNT_SLOTS = 0, 1, 2, 3, 4, 5, 6, 8
+OVF_BARRIER_TIMEOUT = 64   # STTM_OVF_BARRIER_TIMEOUT
 EVENT_SLOTS = 5            # STTM_EVENT_SLOTS
 BATCH_MAX = 16             # STTM_BATCH_MAX
 

@@ -35,14 +35,16 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > mt for d in deps)
 
 
-def source_tag():
-    """Short hash of every source the library is built from: baked into the library (sttm_build_tag) so that measurements
-    committed under profiles/ can say which build they were taken on."""
+def source_tag(extra_flags=()):
+    """Short hash of every source the library is built from AND of the compile flags: baked into the library (sttm_build_tag)
+    so that measurements committed under profiles/ can say which build they were taken on (two builds of the same sources
+    with different flags -- STTM_NT_STREAM, extra_flags -- report different tags and do not share object files)."""
     import hashlib
     h = hashlib.sha256()
     for f in sorted(SOURCES) + sorted(HEADERS):
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())
+    h.update(("\0".join(list(FLAGS) + sorted(extra_flags))).encode())
     return h.hexdigest()[:12]
 
 
@@ -56,7 +58,7 @@ def build(force=False, verbose=False, extra_flags=(), dev=False):
     if dev:
         extra_flags = tuple(extra_flags) + ("-DSTTM_DEV",)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
-    tag = source_tag() + ("-dev" if dev else "")
+    tag = source_tag(extra_flags) + ("-dev" if dev else "")
     tag_file = os.path.join(objdir, ".build_tag")
     old_tag = open(tag_file).read().strip() if os.path.exists(tag_file) else ""
     objs, jobs = [], []
@@ -65,7 +67,8 @@ def build(force=False, verbose=False, extra_flags=(), dev=False):
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
         extra = [f'-DSTTM_BUILD_TAG="{tag}"'] if src == "api.hip" else []
-        if force or _stale(o, [s] + hdrs) or (extra and old_tag != tag):
+        # a changed tag = changed sources OR changed flags: every object is rebuilt (the flags apply to all of them)
+        if force or _stale(o, [s] + hdrs) or old_tag != tag:
             jobs.append([_hipcc(), *FLAGS, *extra_flags, *extra, "-c", s, "-o", o])
     def run(cmd):
         if verbose:

@@ -25,7 +25,11 @@
 // that is not connected components), so the columns must all run the same number of iterations: every column
 // probes to its fixed point and records after which iterations it was idempotent; the global count K is the first
 // iteration at which all columns were; a column whose fixed point came later replays exactly K iterations.
+#include <atomic>
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <tuple>
 
 #include "sttm_kernels.h"
 #include "sttm_pairs.inc"
@@ -432,7 +436,11 @@ __device__ __forceinline__ bool column_labels(const TemporalArgs& a, int r, cons
     bool alive = true;
     if constexpr (MODE == COL_FUSED) {
         alive = grid_barrier(reinterpret_cast<unsigned long long*>(a.bar + 4), R, history, &sh->ok, &sh->kfast);
-        if (!alive) ovf += 1;
+        if (!alive) {
+            ovf += 1;
+            // distinct from list overflows (sticky bit 1 of the flag word): the host retries on the two-launch path
+            if (tid == 0) __hip_atomic_fetch_or(a.bar + 1, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     STTM_LBL_TICK(4);
     int nodes = 0, leafnodes = 0, survivors = 0;
@@ -580,14 +588,21 @@ __global__ void __launch_bounds__(kColThreads) k_col_labels(const TemporalArgs a
     column_labels_any<MODE>(a, g, blockIdx.x, smem_raw, cap);
 }
 
-// Device facts the residency decisions need (queried once per process; the C ABI serves one device per process the way
-// torch.distributed runs it -- one process per GPU).
+// Device facts the residency decisions need, cached per DEVICE (a process may drive several: the answer for the device that
+// happened to be current at first use is not the answer for the others).
+constexpr int kMaxDevices = 64;
 static int device_cus() {
-    static const int n = [] {
-        int dev = 0, v = 0;
-        return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 0;
-    }();
-    return n;
+    static std::atomic<int> cache[kMaxDevices];          // 0 = not asked yet
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return 0;
+    if (dev < kMaxDevices) {
+        const int c = cache[dev].load(std::memory_order_relaxed);
+        if (c > 0) return c;
+    }
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 0;
+    if (dev < kMaxDevices) cache[dev].store(v, std::memory_order_relaxed);
+    return v;
 }
 static int device_cus_or(int dflt) { const int n = device_cus(); return n > 0 ? n : dflt; }
 
@@ -848,9 +863,24 @@ bool labels_can_fuse(const TemporalArgs& a, int n_videos) {
     if (cus <= 0) return false;
     const int cap = col_kernel_cap(a);
     const size_t smem = col_lds_bytes(cap, cap > 0 ? a.max_slots : 0, cap > 0 ? a.T : 0);
+    // the occupancy query is a driver call: asked once per (device, block size, LDS bytes), not on every merge
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_col_labels<COL_FUSED>, col_threads(a), smem) != hipSuccess || per_cu < 1)
-        return false;
+    {
+        static std::mutex mu;
+        static std::map<std::tuple<int, int, size_t>, int> memo;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const auto key = std::make_tuple(dev, col_threads(a), smem);
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = memo.find(key);
+        if (it == memo.end()) {
+            int v = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_col_labels<COL_FUSED>, col_threads(a), smem) != hipSuccess) v = 0;
+            it = memo.emplace(key, v).first;
+        }
+        per_cu = it->second;
+    }
+    if (per_cu < 1) return false;
     // a quarter of what the API promises: it answers one block per CU too many for kernels with > 80 SGPRs
     // (MI355X_MICROARCH.md, residency), and other streams may hold part of the device
     return (long long)a.R * n_videos <= (long long)per_cu * cus / 4;
@@ -947,7 +977,10 @@ __global__ void __launch_bounds__(256, TypeInfo<T>::lowp ? 6 : 8) k_group_mean(c
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.bar) {     // (a.bar is null when this kernel only re-merges another tensor: sttm_quadtree_apply)
         // the label stage left (overflow << 56 | N' << 24 | columns) in one word; complete at this kernel boundary
         const unsigned long long all = __hip_atomic_load(reinterpret_cast<unsigned long long*>(a.bar + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        publish_counts(a, (int)((all >> 24) & 0xffffffffull), (int)(all >> 56));
+        const int timed_out = (ld_agent(a.bar + 1) & 2) ? STTM_OVF_BARRIER_TIMEOUT : 0;     // the fused label stage's grid barrier gave up
+        int ovf = (int)(all >> 56);
+        if (ovf >= STTM_OVF_BARRIER_TIMEOUT) ovf = STTM_OVF_BARRIER_TIMEOUT - 1;
+        publish_counts(a, (int)((all >> 24) & 0xffffffffull), ovf | timed_out);
     }
     const int stride = S * nwave, me = s * nwave + wave;
     // output rows before this frame: every wave sums frame_cnt[0..t) for itself (no LDS, no workgroup barrier)

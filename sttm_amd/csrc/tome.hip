@@ -824,8 +824,13 @@ __global__ void __launch_bounds__(256) k_tome_merge(const void* __restrict__ x, 
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
-        // scatter_add accumulates in fp32 and rounds the sum ONCE to the tensor dtype (ATen's expanded-index path, checked on
-        // bf16 against the CPU operator); the products x * size are tensors of their own and are rounded individually
+        // 16-bit inputs: the sum of a destination's sources is accumulated in fp32 and rounded ONCE to the tensor dtype.  This is
+        // a DETERMINISTIC CHOICE, not the reference's only behaviour: ATen's CPU scatter_add takes that route on its
+        // expanded-index path (FBGEMM / OpenMP builds: the build that generated tests/golden/tome16_*, recorded in their meta),
+        // while its CUDA/HIP kernel and CPU builds without that path round after every atomic add, on the GPU in a
+        // nondeterministic order.  For destinations with >= 2 sources the two differ by 1-2 ulp of the dtype, which is the spread
+        // of the reference itself from run to run; the parity tests compare such rows with an ulp tolerance, not bit equality.
+        // The products x * size are tensors of their own and are rounded individually (both routes agree on that).
         const float sb = size ? size[tok] : 1.f;
         float stot = sb;
         for (int m = 0; m < cnt; ++m) {

@@ -30,15 +30,26 @@ def _next_seq(n=1):
     return first
 
 
+_GUARD_TIMEOUT_S = 120.0
+
+
 def _stream_guard(key):
-    """Two host threads must not issue merges on the SAME stream at the same time: they would share that stream's scratch
-    and pinned count buffer.  (Each thread on its own stream is fine -- see tests/test_hip_parity.py.)  Raises instead of racing."""
+    """Two host threads that issue merges on the SAME stream (the default stream of a threaded inference server, say) share
+    that stream's scratch and pinned count buffer: their calls are SERIALISED here -- the scratch is stream-ordered and the
+    pinned counts are consumed before the lock is released, so taking turns is correct.  (Threads on their own streams run
+    concurrently -- tests/test_hip_parity.py.)  A wait longer than _GUARD_TIMEOUT_S raises instead of hanging forever.
+    Lock entries live as long as the stream's scratch does (pruned together with _ws_cache)."""
     lock = _stream_locks.get(key)
     if lock is None:
-        lock = _stream_locks.setdefault(key, threading.Lock())
-    if not lock.acquire(blocking=False):
-        raise RuntimeError("sttm_amd: another host thread is inside a merge call on this same stream; give every thread "
-                           "its own torch.cuda.Stream (the scratch and the pinned counts are per stream)")
+        with _seq_lock:
+            lock = _stream_locks.setdefault(key, threading.Lock())
+            if len(_stream_locks) > 4 * max(_ws_cache.limit, _pinned_counts.limit):
+                for k in [k for k, l in _stream_locks.items() if k not in _ws_cache and k != key and not l.locked()]:
+                    del _stream_locks[k]
+    if not lock.acquire(timeout=_GUARD_TIMEOUT_S):
+        raise RuntimeError("sttm_amd: waited %.0f s for another host thread inside a merge call on this same stream "
+                           "(give every thread its own torch.cuda.Stream: the scratch and the pinned counts are per stream)"
+                           % _GUARD_TIMEOUT_S)
     return lock
 
 
@@ -94,11 +105,33 @@ def _wait(lib, host_row, seq, stream, counts_row):
         host_row.copy_(counts_row, non_blocking=True)  # fallback: classic D2H + stream sync
         stream.synchronize()
     cnt = host_row.tolist()
+    if cnt[_lib.CNT_OVERFLOW] & _lib.OVF_BARRIER_TIMEOUT:
+        raise BarrierTimeout("libsttm_hip: the fused label stage's grid barrier timed out (other streams held the CUs): counts=%s" % cnt)
     if cnt[_lib.CNT_OVERFLOW]:
         raise RuntimeError("libsttm_hip: internal list overflow (please report): counts=%s" % cnt)
     return cnt
 
 
+class BarrierTimeout(RuntimeError):
+    """The one-launch label stage needs its R column workgroups co-resident; when other work holds the CUs for longer than its
+    2 s bound it gives up and says so.  The wrappers below then switch the process to the two-launch label path (no residency
+    assumption) and repeat the call."""
+
+
+def _retry_without_fused_labels(fn):
+    def wrapped(*a, **kw):
+        try:
+            return fn(*a, **kw)
+        except BarrierTimeout as e:
+            import warnings
+            warnings.warn(str(e) + " -- switching to the two-launch label path (no_fuse=1) and repeating the call")
+            _lib.configure(no_fuse=1)
+            return fn(*a, **kw)
+    wrapped.__name__, wrapped.__doc__ = fn.__name__, fn.__doc__
+    return wrapped
+
+
+@_retry_without_fused_labels
 def quadtree_merge_raw(x, threshold, temporal_thresh, root_level, weighted_avg, head_dim, slow_ver=False, return_ctx=False,
                        feat_dest=None, events=None):
     """Launch the merge of one video and return the worst-case-sized outputs plus the host counts (only the slots CNT_OUT and
@@ -168,6 +201,7 @@ def _apply_side_tensor(v, ctx, root_level, sum_mode):
     return out
 
 
+@_retry_without_fused_labels
 def get_quadtree_features_batch(videos, threshold, temporal_thresh=-1.0, root_level=0, weighted_avg=False,
                                 slow_ver=False, head_dim=None, events=None):
     """Extension (not in the reference, whose API is one video per call): merge a LIST of videos and return the list of

@@ -50,7 +50,11 @@ def main():
         assert feat.dtype == dt and idx.dtype == torch.int64
         np.savez_compressed(os.path.join(HERE, case["name"] + ".npz"),
                             x_thwc=to_np(x.permute(0, 2, 3, 1)), feat=to_np(feat), idx=to_np(idx),
-                            meta=json.dumps(dict(case, fn="tome")))
+                            meta=json.dumps(dict(case, fn="tome", torch=torch.__version__,
+                                                 # ATen's bf16/fp16 CPU scatter_add rounds once (expanded-index path) only in builds with
+                                                 # FBGEMM + OpenMP; other builds round per add (csrc/tome.hip, k_tome_merge)
+                                                 torch_parallel=torch.__config__.parallel_info().splitlines()[:4],
+                                                 torch_has_fbgemm="USE_FBGEMM=ON" in torch.__config__.show())))
         print(case["name"], tuple(feat.shape))
 
 

@@ -147,3 +147,39 @@ def test_feature_file_loaders_refuse_the_cpu(tmp_path):
         load_llavavideo_features(str(p), "cpu")
     with pytest.raises(ValueError):
         load_qwen2vl_features(str(p), "cuda:0")              # a [T, tokens, C] file is not the Qwen2-VL [T, H, W, C] format
+
+
+def test_barrier_timeout_switches_to_the_two_launch_label_path(monkeypatch):
+    """Host logic of the round-2 advisor finding: a timed-out grid barrier of the fused label stage is reported through its own
+    bit of the overflow slot (include/sttm_hip.h: STTM_OVF_BARRIER_TIMEOUT) and the wrapper repeats the call with no_fuse=1."""
+    import warnings
+    from sttm_amd import quadtree_interface as QI
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "sttm_hip.h")).read()
+    assert re.search(r"#define\s+STTM_OVF_BARRIER_TIMEOUT\s+64\b", hdr) and _lib.OVF_BARRIER_TIMEOUT == 64
+    configured = []
+    monkeypatch.setattr(_lib, "configure", lambda **kw: configured.append(kw))
+    calls = []
+
+    @QI._retry_without_fused_labels
+    def merge(x):
+        calls.append(x)
+        if len(calls) == 1:
+            raise QI.BarrierTimeout("timed out")
+        return x + 1
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert merge(41) == 42
+    assert calls == [41, 41] and configured == [{"no_fuse": 1}] and w and "two-launch" in str(w[0].message)
+
+    @QI._retry_without_fused_labels
+    def overflow(x):
+        raise RuntimeError("internal list overflow")
+    with pytest.raises(RuntimeError):
+        overflow(1)                      # any other failure is not retried
+    assert configured == [{"no_fuse": 1}]
+
+
+def test_build_tag_depends_on_the_compile_flags():
+    from sttm_amd import build
+    assert build.source_tag() == build.source_tag(())
+    assert build.source_tag(("-DSTTM_DEV",)) != build.source_tag()

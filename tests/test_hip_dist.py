@@ -3,6 +3,7 @@ group, the sharding and both collectives of sttm_amd.distributed with the HIP me
 self-spawn + --validate mode at a small size.  (World size 2 of the same code runs on CPU with gloo: test_sharding_gloo.py.)"""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -43,11 +44,19 @@ print("DIST_OK")
 '''
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 def _torchrun(nproc, script_args, env=None, timeout=600):
     e = dict(os.environ, STTM_REPO=REPO, HSA_ENABLE_IPC_MODE_LEGACY="0")
     e.update(env or {})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
-           "--master-port", "29517"] + script_args
+           "--master-port", str(_free_port())] + script_args
     return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=e, cwd=REPO)
 
 
@@ -61,7 +70,7 @@ def test_one_rank_torchrun_through_both_collectives(tmp_path):
 def test_bench_validate_mode_under_torchrun():
     """bench.py as the driver launches it (torchrun, one rank here), small sizes, with the index gather of --validate."""
     r = _torchrun(1, [os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--videos-per-step", "8", "--frames", "16",
-                      "--profile-calls", "8", "--no-cpu-baseline", "--no-extensions", "--validate"])
+                      "--profile-calls", "8", "--no-cpu-baseline", "--no-extensions", "--no-configs", "--validate"])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["validate"]["cross_rank_index_match"] is True

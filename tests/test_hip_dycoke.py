@@ -142,4 +142,6 @@ def test_dycoke_16bit_golden_vectors(name):
             for p in got ^ exp:
                 assert abs(float(sims[f, p]) - cut) <= 2 * ulp * max(1.0, abs(cut)), (f, p, float(sims[f, p]), cut)
     print(f"{name}: {agree}/{total} kept tokens identical")
-    assert agree >= 0.9 * total
+    # measured (round 3, MI355X): 877/878 and 1173/1176 on the bf16 vectors, all on the fp16 ones -- every difference is a token
+    # whose similarity equals the cut value within 2 ulps (asserted above); the bound is those counts with slack: >= 99.5 %
+    assert total - agree <= max(3, total // 200), f"{name}: {total - agree} of {total} kept tokens differ"

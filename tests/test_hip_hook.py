@@ -237,9 +237,10 @@ def test_hooks_on_a_bf16_model(pattern):
             hm, _, idx = patch_hooks.dycoke_merge(hs, pos, start, length, T, dycoke_ttm, 0.7)
             rm, _, ridx = patch_hooks.dycoke_merge(hs.cpu(), pos.cpu(), start, length, T, D.dycoke_ttm, 0.7)
             assert hm.shape == rm.shape and out.shape[1] == hm.shape[1]
-            agree = len(set(idx.cpu().tolist()) & set(ridx.tolist())) / len(ridx)
-            print(f"dycoke-stage1 on bf16: kept-token agreement {agree:.4f}")
-            assert agree >= 0.9                                         # bf16 similarities tie at the cut; see test_hip_dycoke.py
+            got, ref = set(idx.cpu().tolist()), set(ridx.tolist())
+            agree = len(got & ref) / len(ridx)
+            print(f"dycoke-stage1 on bf16: kept-token agreement {agree:.4f}; only here {sorted(got - ref)[:8]}, only in the oracle {sorted(ref - got)[:8]}")
+            assert agree >= 0.995                                       # measured 0.9984: bf16 similarities tie at the cut; see test_hip_dycoke.py
         else:
             hm, _, idx = patch_hooks.quadtree_merge_llava(hs, pos, start, length, T, get_quadtree_features, 0.85, 0.55, 1, False)
             rm, _, ridx = patch_hooks.quadtree_merge_llava(hs.cpu(), pos.cpu(), start, length, T, O.get_quadtree_features, 0.85, 0.55, 1, False)

@@ -111,6 +111,9 @@ ORACLE_CASES = [
     (180, 1024, 14, 14, 33, torch.float32, 0.94, 0.82, 1, False),  # C5: MLVU 180 frames (run_vidqa.sh:89)
     (180, 1024, 14, 14, 34, torch.bfloat16, 0.94, 0.82, 1, False),
     (4200, 16, 14, 14, 35, torch.float32, 0.85, 0.55, 1, False),   # 67 200 label slots per column: past the 16-bit slot ids of round 1
+    # the production dtype / widths at FULL clip length (what the hook hands over: quadtree_attn_monkey_patch.py:98, bf16 hidden states)
+    (128, 3584, 14, 14, 42, torch.bfloat16, 0.85, 0.55, 1, False), # LLaVA-Video-7B / Qwen2-7B width, Video-MME preset
+    (180, 8192, 14, 14, 43, torch.bfloat16, 0.94, 0.82, 1, False), # 72B width, MLVU preset (BASELINE config 5)
     # 6-level trees (three levels above the register blocks): root cells of up to 32 x 32 leaves
     (3, 256, 36, 64, 36, torch.float32, 0.85, 0.55, 0, False),
     (3, 128, 40, 40, 37, torch.bfloat16, 0.80, 0.50, 0, False),
@@ -236,32 +239,41 @@ def test_label_stage_paths_give_identical_results(opts):
         _lib.configure(**defaults)
 
 
-def test_same_stream_from_two_threads_is_refused_not_raced():
+def test_same_stream_from_two_threads_is_serialised_not_raced():
     """The scratch and the pinned counts are per stream: a second host thread entering a merge on the SAME stream while another
-    is inside gets a RuntimeError instead of sharing them."""
-    import threading
+    is inside WAITS for it (round-2 advisor finding: it used to raise), then runs and returns the same result."""
+    import threading, time
     from sttm_amd import get_quadtree_features, quadtree_interface as QI
     from sttm_amd.synth import synth_video
     dev = _dev()
     x = synth_video(8, 64, 14, 14, seed=3).to(dev)
     key = (dev, torch.cuda.current_stream(dev).cuda_stream)
-    get_quadtree_features(x, 0.85, 0.55, 1)
+    ref = get_quadtree_features(x, 0.85, 0.55, 1)
     lock = QI._stream_guard(key)                 # stand-in for "another thread is inside the call"
-    errs = []
+    out, errs = [], []
 
     def other():
         try:
             with torch.cuda.stream(torch.cuda.current_stream(dev)):
-                get_quadtree_features(x, 0.85, 0.55, 1)
-        except RuntimeError as e:
-            errs.append(str(e))
+                out.append(get_quadtree_features(x, 0.85, 0.55, 1))
+        except Exception as e:      # noqa: BLE001
+            errs.append(repr(e))
+    th = threading.Thread(target=other)
     try:
-        th = threading.Thread(target=other)
-        th.start(); th.join()
+        th.start()
+        time.sleep(0.3)
+        assert th.is_alive() and not out and not errs          # blocked behind the holder, neither failed nor raced ahead
     finally:
         lock.release()
-    assert errs and "same stream" in errs[0]
-    get_quadtree_features(x, 0.85, 0.55, 1)      # and the stream is usable again
+    th.join(30)
+    assert not th.is_alive() and not errs and len(out) == 1
+    assert all(torch.equal(a, b) for a, b in zip(out[0], ref))
+    # the lock table does not grow with every stream ever used
+    for _ in range(80):
+        with torch.cuda.stream(torch.cuda.Stream(dev)):
+            get_quadtree_features(x, 0.85, 0.55, 1)
+    torch.cuda.synchronize()
+    assert len(QI._stream_locks) <= 4 * max(QI._ws_cache.limit, QI._pinned_counts.limit) + 1
 
 
 def test_batched_extension_equals_per_video_calls():
@@ -478,8 +490,22 @@ def _tome16_agreement(f, i, ef, ei, what):
     a, b = gf[pg].float(), xf[px].float()
     bad = ((a - b).abs() / b.abs().clamp_min(1.0) > tol).any(dim=1)
     ida, fa = len(both) / len(xi), 1.0 - float(bad.float().mean())
-    print(f"{what}: id agreement {ida:.4f} ({len(both)}/{len(xi)}), rows within 2 ulp {fa:.4f}")
+    only_g, only_x = sorted(set(gi.tolist()) - set(xi.tolist())), sorted(set(xi.tolist()) - set(gi.tolist()))
+    print(f"{what}: id agreement {ida:.4f} ({len(both)}/{len(xi)}), rows within 2 ulp {fa:.4f}"
+          + (f"; ids only here {only_g[:8]}, only in the reference {only_x[:8]}" if only_g or only_x else "")
+          + (f"; rows beyond 2 ulp at ids {sel[bad].tolist()[:8]}" if bool(bad.any()) else ""))
     return ida, fa
+
+
+def _assert_tome16(ida, fa, n_ref, what):
+    """What is measured on the committed vectors and the oracle cases (round 3, MI355X): at most 1 kept id in 177..471 and 3 in
+    1 882 differ (ties of the rounded 16-bit scores at the top-r cut: the reference's argsort is unstable, ours takes the smaller
+    index), and at most 2 rows in ~200 / 6 in 1 879 leave the 2-ulp band (the b-tokens that received a different source).
+    The bounds below are those counts with one more tie of slack -- >= 99.5 % ids / >= 99 % rows once n >= 400."""
+    id_slack = max(1, -(-n_ref * 2 // 1000))              # ceil(0.2 %)
+    row_slack = max(2, -(-n_ref * 5 // 1000))             # ceil(0.5 %)
+    assert round((1.0 - ida) * n_ref) <= id_slack, f"{what}: {round((1.0 - ida) * n_ref)} of {n_ref} kept ids differ (allowed {id_slack})"
+    assert round((1.0 - fa) * n_ref) <= row_slack, f"{what}: {round((1.0 - fa) * n_ref)} of {n_ref} rows beyond 2 ulp (allowed {row_slack})"
 
 
 @pytest.mark.parametrize("path", case_paths(["tome16_"]), ids=os.path.basename)
@@ -495,7 +521,7 @@ def test_tome_16bit_golden_vectors(path):
     ida, fa = _tome16_agreement(feat, idx, c["feat"], c["idx"], c["name"])
     if m["ratio"] == 0.5:
         assert torch.equal(idx.cpu(), c["idx"])
-    assert ida >= 0.97 and fa >= 0.97
+    _assert_tome16(ida, fa, c["idx"].numel(), c["name"])
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
@@ -510,7 +536,7 @@ def test_tome_16bit_against_oracle(dtype, T, C, ratio):
     f, i = get_tome_features(x.to(_dev()), ratio, "video", 1)
     assert f.dtype == dtype and f.shape == ef.shape
     ida, fa = _tome16_agreement(f, i, ef, ei, f"{dtype} T={T} C={C} r={ratio}")
-    assert ida >= 0.97 and fa >= 0.97
+    _assert_tome16(ida, fa, ei.numel(), f"{dtype} T={T} C={C} r={ratio}")
 
 
 def test_tome_16bit_match_scores_against_dense_reference():
@@ -689,13 +715,13 @@ def test_tome_16bit_match_kernel_variants(mode):
             ida, fa = _tome16_agreement(feat, idx, c["feat"], c["idx"], f"{mode} {c['name']}")
             if m["ratio"] == 0.5:
                 assert torch.equal(idx.cpu(), c["idx"])
-            assert ida >= 0.97 and fa >= 0.97
+            _assert_tome16(ida, fa, c["idx"].numel(), f"{mode} {c['name']}")
         for dtype in (torch.bfloat16, torch.float16):
             x = synth_video(32, 1024, 14, 14, seed=332, dtype=dtype)
             ef, ei = O.get_tome_features(x, 0.7, "video", 1)
             f, i = get_tome_features(x.to(_dev()), 0.7, "video", 1)
             ida, fa = _tome16_agreement(f, i, ef, ei, f"{mode} {dtype}")
-            assert ida >= 0.97 and fa >= 0.97
+            _assert_tome16(ida, fa, ei.numel(), f"{mode} {dtype}")
     finally:
         _lib.configure(tome_split=1)
 

@@ -19,7 +19,7 @@ for f in sorted(glob.glob("gpurun_out/${TAG}_bench*.json")) :
     except Exception as e:
         print(f, "unreadable", e); continue
     r = d["roofline"]
-    print(f.split("/")[-1], "value", d["value"], "device_ms", r["device_ms_per_video"], "frac", r["frac"], r["kernel_ms"],
+    print(f.split("/")[-1], "value", d["value"], "wall_ms", r["wall_ms_per_video"], "frac", r["frac"], r["kernel_ms"],
           {k: d[k]["value"] for k in ("batched_extension", "threaded_dropin_extension", "tome_extension") if k in d})
 PY
 cat gpurun_out/${TAG}_prof_kernels.md

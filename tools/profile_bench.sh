@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 mkdir -p "$REPO/gpurun_out"
 cd /tmp
 rm -rf /tmp/prof_$TAG
-timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o bench -- python "$REPO/bench.py" --no-cpu-baseline --no-extensions "$@" \
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o bench -- python "$REPO/bench.py" --no-cpu-baseline --no-extensions --no-configs "$@" \
     > "$REPO/gpurun_out/${TAG}_bench.json" 2> "$REPO/gpurun_out/${TAG}_err.log"
 cd "$REPO"
 DB=$(find /tmp/prof_$TAG -name '*.db' | head -1)
