@@ -24,7 +24,7 @@ int fail(int code, const char* fmt, ...) {
 // Tuning / test switches: defaults from STTM_<KEY> environment variables, read ONCE; sttm_configure overrides them.
 // None of them changes results.
 struct Config {
-    int pairs_seg, pairs_nt, gm_split, label_nt, vec16, vec32, fold_kb, fold_labels, no_fuse, force_gmem_labels, tome_split;
+    int pairs_seg, pairs_nt, pairs_var, gm_var, gm_split, label_nt, vec16, vec32, fold_kb, fold_labels, no_fuse, force_gmem_labels, tome_split;
 };
 int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
@@ -35,6 +35,8 @@ Config& config() {
         Config d;
         d.pairs_seg = env_int("STTM_PAIRS_SEG", 0);
         d.pairs_nt = env_int("STTM_PAIRS_NT", 0);
+        d.pairs_var = env_int("STTM_PAIRS_VAR", 0);
+        d.gm_var = env_int("STTM_GM_VAR", 0);
         d.gm_split = env_int("STTM_GM_SPLIT", 0);
         d.label_nt = env_int("STTM_LABEL_NT", 1024);
         d.vec16 = env_int("STTM_VEC16", 0);
@@ -392,6 +394,7 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
     ta.dims = p.dims;
     ta.dtype = dtype; ta.vec = row_vec(C, dtype, vec, dense, all_bits % 32 == 0, head_dim);
     sttm::pairs_shape(T, p.R, cfg.fold_labels && !slow_ver, cfg.pairs_seg, cfg.pairs_nt, &ta.pairs_seg, &ta.pairs_nt);
+    ta.pairs_var = cfg.pairs_var;
     ta.label_nt = (cfg.label_nt == 256 || cfg.label_nt == 512) ? cfg.label_nt : 1024;
     ta.temporal_thresh = temporal_thresh;
     ta.weighted_avg = weighted_avg ? 1 : 0;
@@ -409,7 +412,7 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
     ta.ecap_magic = 0xffffffffu / (unsigned)p.ecap + 1u;
     ta.col_mask = b.col_mask; ta.col_arrive = b.col_arrive; ta.frame_cnt = b.frame_cnt; ta.bar = b.bar;
     ta.colscratch = b.colscratch;
-    ta.gm_split = gm_split_for(T); ta.lab_row = b.lab_row; ta.gcnt = b.gcnt; ta.cgeo = b.cgeo;
+    ta.gm_split = gm_split_for(T); ta.gm_var = cfg.gm_var; ta.lab_row = b.lab_row; ta.gcnt = b.gcnt; ta.cgeo = b.cgeo;
     ta.counts = counts;
     ta.counts_host = counts_host; ta.seq = seq;
     ta.feat_out = feat_out[0]; ta.npatch_out = npatch_out[0]; ta.tlbr_out = tlbr_out[0];
@@ -476,7 +479,7 @@ int sttm_configure(const char* key, int value) {
     if (!key) return fail(STTM_ERR_ARG, "null key");
     Config& c = config();
     struct { const char* name; int* slot; } keys[] = {
-        {"pairs_seg", &c.pairs_seg}, {"pairs_nt", &c.pairs_nt}, {"gm_split", &c.gm_split}, {"label_nt", &c.label_nt},
+        {"pairs_seg", &c.pairs_seg}, {"pairs_nt", &c.pairs_nt}, {"pairs_var", &c.pairs_var}, {"gm_var", &c.gm_var}, {"gm_split", &c.gm_split}, {"label_nt", &c.label_nt},
         {"vec16", &c.vec16}, {"vec32", &c.vec32}, {"fold_kb", &c.fold_kb}, {"fold_labels", &c.fold_labels}, {"no_fuse", &c.no_fuse}, {"tome_split", &c.tome_split},
         {"force_gmem_labels", &c.force_gmem_labels},
     };

@@ -617,8 +617,8 @@ static int device_cus_or(int dflt) { const int n = device_cus(); return n > 0 ? 
 // ---------------------------------------------------------------------------------------------------
 struct PairShared { int last, pad0, pad1, pad2; };
 
-template <typename T, int VEC>
-__global__ void __launch_bounds__(1024) k_pairs(const TemporalArgs a0, const BatchPtrs bp) {
+template <typename T, int VEC, int UNRB, bool LEAN>
+__device__ __forceinline__ void pairs_body(const TemporalArgs& a0, const BatchPtrs& bp) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const LevelDims& g = a0.dims;          // see k_col_labels
     TemporalArgs a = a0;
@@ -645,8 +645,12 @@ __global__ void __launch_bounds__(1024) k_pairs(const TemporalArgs a0, const Bat
     const PairGeo geo = {col.Y1, col.X1, col.aw};
     const int tid = threadIdx.x;
     if (tid == 0) ps->last = 0;
-    if (a.fold_labels) pair_run<T, VEC, false, true>(a, geo, r, t0, np, L, smem_raw + sizeof(PairShared));
-    else pair_run<T, VEC, false, false>(a, geo, r, t0, np, L, smem_raw + sizeof(PairShared));
+    if constexpr (LEAN) {          // no folded label stage, no per-head cosine: the common call
+        pair_run<T, VEC, false, false, UNRB, false>(a, geo, r, t0, np, L, smem_raw + sizeof(PairShared));
+        return;
+    }
+    if (a.fold_labels) pair_run<T, VEC, false, true, UNRB>(a, geo, r, t0, np, L, smem_raw + sizeof(PairShared));
+    else pair_run<T, VEC, false, false, UNRB>(a, geo, r, t0, np, L, smem_raw + sizeof(PairShared));
     STTM_K2_TICK(2);
     if (a.fold_labels && tid == 0) {
         const int old = __hip_atomic_fetch_add(a.col_arrive + r, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -661,6 +665,12 @@ __global__ void __launch_bounds__(1024) k_pairs(const TemporalArgs a0, const Bat
     column_labels_any<COL_FUSED>(a, g, r, smem_raw, a.fold_cap);
 #undef STTM_K2_TICK
 }
+// any block size up to 1024 (runs of pairs, folded label stage)
+template <typename T, int VEC>
+__global__ void __launch_bounds__(1024) k_pairs(const TemporalArgs a0, const BatchPtrs bp) { pairs_body<T, VEC, 64, false>(a0, bp); }
+// the default shape: one pair per 256-thread workgroup, registers bounded for OCC waves per SIMD
+template <typename T, int VEC, int OCC, int UNRB>
+__global__ void __launch_bounds__(256, OCC) k_pairs256(const TemporalArgs a0, const BatchPtrs bp) { pairs_body<T, VEC, UNRB, true>(a0, bp); }
 
 static size_t pairs_smem(const TemporalArgs& a) {
     return sizeof(PairShared) + pair_lds_bytes(a.pairs_seg, a.rc_stride, a.ecap);
@@ -677,6 +687,22 @@ hipError_t launch_pairs(const TemporalArgs& a, const BatchPtrs& bp, int n_videos
     }
     const int nt = a.pairs_nt;
 #define STTM_LAUNCH_PAIRS(TT, VV) hipLaunchKernelGGL((k_pairs<TT, VV>), dim3(grid, n_videos), dim3(nt), smem, stream, a, bp)
+#define STTM_LAUNCH_PAIRS256(TT, VV, OCC, UB) hipLaunchKernelGGL((k_pairs256<TT, VV, OCC, UB>), dim3(grid, n_videos), dim3(256), smem, stream, a, bp)
+    // default shape (one pair per 256-thread workgroup, whole-vector cosine, stand-alone label stage): the lean kernel --
+    // rows through buffer descriptors with scalar bases, registers bounded for 5 waves per SIMD (A/B on MI355X, round 3:
+    // fp32 C=1024 one 32-byte pack per row in flight 16.5 -> ~13.5 us; 16-bit rows 64 bytes per row in flight, bf16 C=3584
+    // 32.8 -> 27.7 us; variants bounded to 6 / 8 waves spilled and were slower).  pairs_var = 9 selects the general kernel.
+    if (nt == 256 && a.pairs_var != 9 && !a.fold_labels && a.n_head == 0) {
+        if (a.dtype == STTM_F32) {
+            if (a.vec == 8) STTM_LAUNCH_PAIRS256(float, 8, 5, 32); else if (a.vec == 4) STTM_LAUNCH_PAIRS256(float, 4, 5, 32);
+            else if (a.vec == 2) STTM_LAUNCH_PAIRS256(float, 2, 5, 32); else STTM_LAUNCH_PAIRS256(float, 1, 5, 32);
+        } else if (a.dtype == STTM_BF16) {
+            if (a.vec == 8) STTM_LAUNCH_PAIRS256(bf16_t, 8, 5, 64); else if (a.vec == 4) STTM_LAUNCH_PAIRS256(bf16_t, 4, 5, 64); else STTM_LAUNCH_PAIRS256(bf16_t, 2, 5, 64);
+        } else {
+            if (a.vec == 8) STTM_LAUNCH_PAIRS256(f16_t, 8, 5, 64); else if (a.vec == 4) STTM_LAUNCH_PAIRS256(f16_t, 4, 5, 64); else STTM_LAUNCH_PAIRS256(f16_t, 2, 5, 64);
+        }
+        return hipGetLastError();
+    }
     if (a.dtype == STTM_F32) {
         if (a.vec == 8) STTM_LAUNCH_PAIRS(float, 8); else if (a.vec == 4) STTM_LAUNCH_PAIRS(float, 4); else if (a.vec == 2) STTM_LAUNCH_PAIRS(float, 2); else STTM_LAUNCH_PAIRS(float, 1);
     } else if (a.dtype == STTM_BF16) {
@@ -1106,8 +1132,221 @@ __global__ void __launch_bounds__(256, TypeInfo<T>::lowp ? 6 : 8) k_group_mean(c
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// K5, round-3 form (k_group_mean2).  Same work split as k_group_mean -- workgroup (t, s), every wave ranks the survivors of
+// frame t and takes the ranks congruent to its id -- rebuilt around what the floor probe (tools/micro/floor_probe.hip) showed:
+// a two-stage gather of 11.2 k rows of 4 KB runs in 14.6 us when the loads of a stage are all in flight together, while the
+// first form spent 22 us: its frame_cnt prefix loop, its bounds branches around the metadata loads and the column geometry of
+// a group survivor each became a round trip of its own.  Here
+//   * stage 1 is ONE round trip: gcnt / meta / cgeo of the frame's slots with clamped indices (no exec-masked branches), the
+//     frame_cnt words of the earlier frames in batches;
+//   * a row's chunks (64 bytes per lane) and, for a group survivor, the labels and boxes of the 64 column slots behind it are
+//     requested together (the column geometry came with stage 1);
+//   * rows go through bounds-checked buffer descriptors (scalar row base, one lane offset, immediates per chunk; lanes past C
+//     read zeros and their stores are dropped): no per-lane 64-bit addresses, no exec masks.
+// The arithmetic is unchanged: members are added in ascending origin order in the input dtype, one rounding per add.
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__device__ __forceinline__ void store_pack_buf(__amdgpu_buffer_rsrc_t rs, uint32_t voff, const Pack<T, VEC>& p) {
+    constexpr int bytes = TypeInfo<T>::bytes * VEC;
+    if constexpr (bytes == 32) {
+        sttm_u32x4 lo, hi;
+        __builtin_memcpy(&lo, &p, 16);
+        __builtin_memcpy(&hi, reinterpret_cast<const char*>(&p) + 16, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(lo, rs, voff, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(hi, rs, voff + 16, 0, 0);
+    } else if constexpr (bytes == 16) {
+        sttm_u32x4 v;
+        __builtin_memcpy(&v, &p, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, 0, 0);
+    } else if constexpr (bytes == 8) {
+        sttm_u32x2 v;
+        __builtin_memcpy(&v, &p, 8);
+        __builtin_amdgcn_raw_buffer_store_b64(v, rs, voff, 0, 0);
+    } else {
+        static_assert(bytes == 4, "packs are 4, 8, 16 or 32 bytes");
+        unsigned v;
+        __builtin_memcpy(&v, &p, 4);
+        __builtin_amdgcn_raw_buffer_store_b32(v, rs, voff, 0, 0);
+    }
+}
+
+struct GmRow { int p, out, n; uint32_t mt, geo; };       // wave-uniform: slot in the frame, output row, group size, box, column geometry
+
+template <typename T, int VEC, int OCC>
+__global__ void __launch_bounds__(256, OCC) k_group_mean2(const TemporalArgs a0, const BatchPtrs bp) {
+    TemporalArgs a = a0;
+    rebase(a, bp, blockIdx.y);
+    constexpr int eb = TypeInfo<T>::bytes;
+    const int lane = threadIdx.x & 63, nwave = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int S = a.gm_split, t = blockIdx.x / S, s = blockIdx.x - t * S;
+    const int HW = a.H * a.W;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.bar) {
+        const unsigned long long all = __hip_atomic_load(reinterpret_cast<unsigned long long*>(a.bar + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int timed_out = (ld_agent(a.bar + 1) & 2) ? STTM_OVF_BARRIER_TIMEOUT : 0;
+        int ovf = (int)(all >> 56);
+        if (ovf >= STTM_OVF_BARRIER_TIMEOUT) ovf = STTM_OVF_BARRIER_TIMEOUT - 1;
+        publish_counts(a, (int)((all >> 24) & 0xffffffffull), ovf | timed_out);
+    }
+    const int stride = S * nwave, me = s * nwave + wave;
+    const unsigned magicW = a.W > 1 ? 0xffffffffu / (unsigned)a.W + 1u : 0u;         // p / W for p < H * W (p * W < 2^32)
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    constexpr int NB = 4;                                       // 64-slot chunks whose metadata is loaded together
+    constexpr int U0 = 64 / (eb * VEC), U = U0 < 1 ? 1 : (U0 > 8 ? 8 : U0);   // chunks of a row in flight per lane (64 bytes; narrow packs: 8 chunks)
+    constexpr int CH = U * 64 * VEC;
+    // rows before this frame: frame_cnt[0 .. t), four words per lane and batch, all requested before the first is used
+    int row0 = 0;
+    for (int f0 = 0; f0 < t; f0 += 256) {
+        int v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int f = f0 + k * 64 + lane;
+            v[k] = a.frame_cnt[f < t ? f : 0];
+            v[k] = f < t ? v[k] : 0;
+        }
+        row0 += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    bool row0_done = false;
+    int j0 = 0;
+    for (int base = 0; base < HW; base += 64 * NB) {
+        int cnt[NB], rank[NB];
+        uint32_t meta[NB], geo[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {                          // clamped indices: no branches between the loads
+            const int p = base + b * 64 + lane;
+            const int pc = p < HW ? p : HW - 1;
+            cnt[b] = a.gcnt[t * HW + pc];
+            meta[b] = a.meta[t * HW + pc];
+            geo[b] = a.cgeo[pc];
+        }
+        if (!row0_done) { row0 = wave_sum_int(row0); row0_done = true; }
+        int nchunk = 0;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (base + b * 64 + lane >= HW) cnt[b] = 0;
+            const unsigned long long m = __ballot(cnt[b] > 0);
+            rank[b] = j0 + nchunk + __popcll(m & lt);
+            nchunk += __popcll(m);
+        }
+        // the survivor of rank j (j0 <= j < j0 + nchunk): exactly one (chunk, lane) holds it
+        auto find = [&](int j) {
+            GmRow r;
+            int cv = 0; uint32_t mv = 0, gv = 0; int l = 0, bsel = 0;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const unsigned long long h = __ballot(cnt[b] > 0 && rank[b] == j);
+                if (h) { l = __ffsll((long long)h) - 1; bsel = b; }
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+                if (bsel == b) { cv = cnt[b]; mv = meta[b]; gv = geo[b]; }
+            r.n = __builtin_amdgcn_readlane(cv, l);
+            r.mt = (uint32_t)__builtin_amdgcn_readlane((int)mv, l);
+            r.geo = (uint32_t)__builtin_amdgcn_readlane((int)gv, l);
+            r.p = base + bsel * 64 + l;
+            r.out = row0 + j;
+            return r;
+        };
+        int jk = j0 + ((me - j0) & (stride - 1));              // first rank >= j0 congruent to me (stride is a power of two)
+        for (; jk < j0 + nchunk; jk += stride) {
+            GmRow r = find(jk);
+#ifdef STTM_DEV
+            if (a.dev.k5_mode == 1) r.n = 1;
+#endif
+            const int n = r.n;
+            const int y1 = a.W > 1 ? (int)__umulhi((unsigned)r.p, magicW) : r.p, x1 = r.p - y1 * a.W;
+            const int y2 = (int)(r.mt >> 16), x2 = (int)(r.mt & 0xffff);
+            const int area = (y2 - y1) * (x2 - x1);
+            const int origin = t * HW + r.p;
+            int patches = area;
+            const void* s0 = (area == 1 && a.xrows) ? a.xrows : a.S;      // 1x1 nodes were not copied out of x
+            auto rdesc = [&](const void* basep, int row, int cb) {
+                const char* q = reinterpret_cast<const char*>(basep) + ((int64_t)row * a.C + cb) * eb;
+                return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(q), 0, (a.C - cb) * eb, 0x00020000);
+            };
+            for (int cb0 = 0; cb0 < a.C; cb0 += CH) {
+                Pack<T, VEC> acc[U];
+                // ---- everything this pass needs first: the row's chunks and, for a group survivor, the 64 slots behind it
+                const __amdgpu_buffer_rsrc_t d = rdesc(s0, origin, cb0);
+#pragma unroll
+                for (int u = 0; u < U; ++u) acc[u] = load_pack_buf<T, VEC>(d, (uint32_t)((u * 64 + lane) * VEC * eb));
+                if (n > 1) {
+                    const Column col = column_from_geo(a, r.geo);
+                    const int slot0 = t * col.A + (y1 - col.Y1) * col.aw + (x1 - col.X1);
+                    int found = 0;
+                    for (int sb = slot0 + 1; found < n - 1 && sb < col.slots; sb += 64) {
+                        const int sl = sb + lane;
+                        const int slc = sl < col.slots ? sl : col.slots - 1;
+                        const int mr0 = slot_to_row(a, col, slc);
+                        const int lb = a.lab_row[mr0];
+                        const uint32_t q = a.meta[mr0];
+                        const int mrow = sl < col.slots ? mr0 : -1;
+                        const bool hit = mrow >= 0 && lb == origin;
+                        unsigned long long mm = __ballot(hit);
+                        if (mm == 0ull) continue;
+                        int ar = 0;
+                        if (hit) {
+                            const int rem = mrow - slot_frame(col, sl) * HW;
+                            const int my1 = a.W > 1 ? (int)__umulhi((unsigned)rem, magicW) : rem, mx1 = rem - my1 * a.W;
+                            ar = ((int)(q >> 16) - my1) * ((int)(q & 0xffff) - mx1);
+                        }
+                        while (mm) {
+                            const int k = __ffsll((long long)mm) - 1;
+                            mm &= mm - 1ull;
+                            const int mr = __builtin_amdgcn_readlane(mrow, k), ak = __builtin_amdgcn_readlane(ar, k);
+                            const void* sm = (ak == 1 && a.xrows) ? a.xrows : a.S;
+                            const __amdgpu_buffer_rsrc_t dm = rdesc(sm, mr, cb0);
+                            Pack<T, VEC> qv[U];
+#pragma unroll
+                            for (int u = 0; u < U; ++u) qv[u] = load_pack_buf<T, VEC>(dm, (uint32_t)((u * 64 + lane) * VEC * eb));
+#pragma unroll
+                            for (int u = 0; u < U; ++u) {
+                                const Pack<T, VEC> prev = acc[u];
+                                pack_fill(acc[u], [&](int e) { return prev.get(e) + qv[u].get(e); });
+                            }
+                            ++found;
+                            if (cb0 == 0) patches += ak;
+                        }
+                    }
+                }
+                if (a.weighted_avg || n > 1) {
+                    const float den = round_to<T>(a.weighted_avg ? (float)patches : (float)n);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const Pack<T, VEC> prev = acc[u];
+                        pack_fill(acc[u], [&](int e) { return prev.get(e) / den; });
+                    }
+                }
+                const __amdgpu_buffer_rsrc_t dout = rdesc(a.feat_out, r.out, cb0);
+#pragma unroll
+                for (int u = 0; u < U; ++u) store_pack_buf<T, VEC>(dout, (uint32_t)((u * 64 + lane) * VEC * eb), acc[u]);
+            }
+            if (a.npatch_out && lane == 0) {
+                a.npatch_out[r.out] = patches;
+                int32_t* o = a.tlbr_out + (int64_t)r.out * 5;
+                o[0] = t; o[1] = y1; o[2] = x1; o[3] = y2; o[4] = x2;
+            }
+        }
+        j0 += nchunk;
+    }
+}
+
 hipError_t launch_group_mean(const TemporalArgs& a, const BatchPtrs& bp, int n_videos, hipStream_t stream) {
     const int grid = a.T * a.gm_split;
+    if (a.gm_var != 9) {          // gm_var = 9 selects the first form of the kernel
+#define STTM_LAUNCH_GM2(TT, VV) hipLaunchKernelGGL((k_group_mean2<TT, VV, 6>), dim3(grid, n_videos), dim3(256), 0, stream, a, bp)
+        if (a.dtype == STTM_F32) {
+            if (a.vec == 8) STTM_LAUNCH_GM2(float, 8); else if (a.vec == 4) STTM_LAUNCH_GM2(float, 4); else if (a.vec == 2) STTM_LAUNCH_GM2(float, 2); else STTM_LAUNCH_GM2(float, 1);
+        } else if (a.dtype == STTM_BF16) {
+            if (a.vec == 8) STTM_LAUNCH_GM2(bf16_t, 8); else if (a.vec == 4) STTM_LAUNCH_GM2(bf16_t, 4); else STTM_LAUNCH_GM2(bf16_t, 2);
+        } else {
+            if (a.vec == 8) STTM_LAUNCH_GM2(f16_t, 8); else if (a.vec == 4) STTM_LAUNCH_GM2(f16_t, 4); else STTM_LAUNCH_GM2(f16_t, 2);
+        }
+#undef STTM_LAUNCH_GM2
+        return hipGetLastError();
+    }
 #define STTM_LAUNCH_GM(TT, VV) hipLaunchKernelGGL((k_group_mean<TT, VV>), dim3(grid, n_videos), dim3(256), 0, stream, a, bp)
     if (a.dtype == STTM_F32) {
         if (a.vec == 8) STTM_LAUNCH_GM(float, 8); else if (a.vec == 4) STTM_LAUNCH_GM(float, 4); else if (a.vec == 2) STTM_LAUNCH_GM(float, 2); else STTM_LAUNCH_GM(float, 1);
