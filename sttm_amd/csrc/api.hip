@@ -595,7 +595,7 @@ int sttm_quadtree_apply(const void* v, int64_t stride_t, int64_t stride_c, int64
     ta.weighted_avg = sum_mode ? 1 : 0;
     ta.S = b.S; ta.xrows = dense ? v : nullptr;
     ta.frame_cnt = b.frame_cnt; ta.lab_row = b.lab_row; ta.gcnt = b.gcnt; ta.cgeo = b.cgeo;
-    ta.meta = b.meta; ta.gm_split = gm_split_for(T);
+    ta.meta = b.meta; ta.gm_split = gm_split_for(T); ta.gm_var = config().gm_var;
     ta.counts = const_cast<int32_t*>(counts);
     ta.feat_out = out;
     sttm::BatchPtrs bp;
