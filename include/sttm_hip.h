@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STTM_ABI_VERSION 4
+#define STTM_ABI_VERSION 5
 
 #define STTM_F32 0
 #define STTM_BF16 1
@@ -120,6 +120,34 @@ int sttm_quadtree_merge_async(const void* x, int64_t stride_t, int64_t stride_c,
                               void* feat_out, int32_t* npatch_out, int32_t* tlbr_out, int32_t* counts,
                               int32_t* counts_host, int seq, void* const* events, void* stream);
 int sttm_wait_counts(const int32_t* counts_host, int seq, int timeout_us);
+
+/*
+ * The same call with its arguments in one block (ABI v5) -- a binding that issues many calls keeps the block and rewrites the
+ * few fields that change (pointers, seq), instead of marshalling 27 scalars per call -- plus EARLY publication of N':
+ * with `early_host` (pinned, device-mapped uint64[STTM_EARLY_SLOTS]) every root-cell column of the label stage stores ONE
+ * 64-bit word  seq << 32 | flags | survivors of the column  into early_host[column] as its last action (a single naturally
+ * aligned system-scope store: no fence, no returning atomic), i.e. one kernel boundary before the group-mean kernel's first
+ * workgroup can publish counts_host.  The call sets n_early = number of columns that will report (0: not used -- more
+ * columns than slots, or early_host NULL); sttm_wait_counts_early sums them.  Flags: bit 31 = the fused label stage's grid
+ * barrier timed out (STTM_OVF_BARRIER_TIMEOUT), bit 30 = an internal list overflowed.
+ */
+#define STTM_EARLY_SLOTS 64
+typedef struct sttm_merge_args {
+    const void* x; int64_t stride_t, stride_c, stride_h, stride_w;
+    int32_t T, C, H, W, dtype;
+    float threshold, temporal_thresh;
+    int32_t root_level, weighted_avg, head_dim, slow_ver;
+    void* workspace; size_t workspace_bytes;
+    void* feat_out; int32_t* npatch_out; int32_t* tlbr_out; int32_t* counts;
+    int32_t* counts_host; int32_t seq;
+    int32_t n_early;                 /* OUT */
+    uint64_t* early_host;
+    void* const* events; void* stream;
+} sttm_merge_args;
+int sttm_quadtree_merge_packed(sttm_merge_args* args);
+/* Waits until either all n_early column words carry `seq` (then out[0] = N', out[1] = overflow flags in the encoding of
+ * counts[STTM_CNT_OVERFLOW]) or counts_host[STTM_CNT_SLOTS-1] == seq (then out = the published counts), like sttm_wait_counts. */
+int sttm_wait_counts_early(const int32_t* counts_host, const uint64_t* early_host, int n_early, int seq, int timeout_us, int32_t* out);
 
 /*
  * Extension (the reference API is one video per call): the same merge for `n_videos` videos of ONE shape, dtype and stride

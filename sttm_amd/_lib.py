@@ -12,11 +12,12 @@ LIB_PATH = os.path.join(_HERE, "lib", "libsttm_hip_dev.so" if os.environ.get("ST
 
 STTM_F32, STTM_BF16, STTM_F16 = 0, 1, 2
 ERR_ARG, ERR_UNSUPPORTED, ERR_LAUNCH, ERR_INDEX, ERR_PARITY, ERR_TIMEOUT = -1, -2, -3, -4, -5, -6
-ABI_VERSION = 4            # STTM_ABI_VERSION of include/sttm_hip.h this binding was written for
+ABI_VERSION = 5            # STTM_ABI_VERSION of include/sttm_hip.h this binding was written for
 CNT_NODES, CNT_CANDIDATES, CNT_EDGES, CNT_OUT, CNT_ITERS, CNT_OVERFLOW, CNT_LEAFNODES, CNT_SLOTS = 0, 1, 2, 3, 4, 5, 6, 8
 OVF_BARRIER_TIMEOUT = 64   # STTM_OVF_BARRIER_TIMEOUT
 EVENT_SLOTS = 5            # STTM_EVENT_SLOTS
 BATCH_MAX = 16             # STTM_BATCH_MAX
+EARLY_SLOTS = 64           # STTM_EARLY_SLOTS
 
 # every symbol include/sttm_hip.h declares, with its ctypes signature
 _vp, _i, _i64, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
@@ -34,6 +35,8 @@ SIGNATURES = {
                                        _vp, _sz, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "sttm_configure": (_i, [ctypes.c_char_p, _i]),
     "sttm_wait_counts": (_i, [_vp, _i, _i]),
+    "sttm_quadtree_merge_packed": (_i, [_vp]),
+    "sttm_wait_counts_early": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sttm_quadtree_apply": (_i, [_vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "sttm_merge_dst_idx": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "sttm_tome_workspace_bytes": (_sz, [_i, _i, _i]),
@@ -47,6 +50,20 @@ SIGNATURES = {
     "sttm_octree_build": (_i, [_vp, _i, _i, _i, _i, ctypes.c_float, _i, _vp, _sz, _vp, _vp, _vp]),
     "sttm_resize_nearest": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
 }
+
+
+
+class MergeArgs(ctypes.Structure):
+    """sttm_merge_args of include/sttm_hip.h (ABI v5): the argument block of sttm_quadtree_merge_packed."""
+    _fields_ = [("x", _vp), ("stride_t", _i64), ("stride_c", _i64), ("stride_h", _i64), ("stride_w", _i64),
+                ("T", ctypes.c_int32), ("C", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("dtype", ctypes.c_int32),
+                ("threshold", _f), ("temporal_thresh", _f),
+                ("root_level", ctypes.c_int32), ("weighted_avg", ctypes.c_int32), ("head_dim", ctypes.c_int32), ("slow_ver", ctypes.c_int32),
+                ("workspace", _vp), ("workspace_bytes", _sz),
+                ("feat_out", _vp), ("npatch_out", _vp), ("tlbr_out", _vp), ("counts", _vp),
+                ("counts_host", _vp), ("seq", ctypes.c_int32), ("n_early", ctypes.c_int32), ("early_host", _vp),
+                ("events", _vp), ("stream", _vp)]
+
 
 _lib = None
 

@@ -313,7 +313,9 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
                 float threshold, float temporal_thresh, int root_level, int weighted_avg, int head_dim, int slow_ver,
                 void* workspace, size_t workspace_stride,
                 void* const* feat_out, int32_t* const* npatch_out, int32_t* const* tlbr_out, int32_t* counts,
-                int32_t* counts_host, int seq, void* const* events, hipStream_t stream) {
+                int32_t* counts_host, int seq, void* const* events, hipStream_t stream,
+                uint64_t* early_host = nullptr, int* n_early = nullptr) {
+    if (n_early) *n_early = 0;
     if (!x || !workspace || !feat_out || !npatch_out || !tlbr_out || !counts) return fail(STTM_ERR_ARG, "null pointer argument");
     if (T < 1 || C < 1) return fail(STTM_ERR_ARG, "T and C must be positive");
     if (dtype < 0 || dtype > 2) return fail(STTM_ERR_ARG, "unknown dtype code %d", dtype);
@@ -415,6 +417,11 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
     ta.gm_split = gm_split_for(T); ta.gm_var = cfg.gm_var; ta.lab_row = b.lab_row; ta.gcnt = b.gcnt; ta.cgeo = b.cgeo;
     ta.counts = counts;
     ta.counts_host = counts_host; ta.seq = seq;
+    // every column reports its survivors to the host itself (single video, a slot per column)
+    if (early_host && n_early && nv == 1 && p.R <= STTM_EARLY_SLOTS) {
+        ta.early_host = reinterpret_cast<unsigned long long*>(early_host);
+        *n_early = p.R;
+    }
     ta.feat_out = feat_out[0]; ta.npatch_out = npatch_out[0]; ta.tlbr_out = tlbr_out[0];
 #ifdef STTM_DEV
     sa.dev = g_dev; ta.dev = g_dev;
@@ -522,6 +529,21 @@ int sttm_quadtree_merge_async(const void* x, int64_t stride_t, int64_t stride_c,
                        counts_host, seq, events, reinterpret_cast<hipStream_t>(stream_));
 }
 
+int sttm_quadtree_merge_packed(sttm_merge_args* g) {
+    if (!g) return fail(STTM_ERR_ARG, "null argument block");
+    const void* x = g->x;
+    void* feat = g->feat_out;
+    int32_t* np = g->npatch_out;
+    int32_t* tl = g->tlbr_out;
+    int n_early = 0;
+    const int rc = merge_group(1, &x, g->stride_t, g->stride_c, g->stride_h, g->stride_w, g->T, g->C, g->H, g->W, g->dtype, g->threshold,
+                               g->temporal_thresh, g->root_level, g->weighted_avg, g->head_dim, g->slow_ver, g->workspace, g->workspace_bytes,
+                               &feat, &np, &tl, g->counts, g->counts_host, g->seq, g->events, reinterpret_cast<hipStream_t>(g->stream),
+                               g->early_host, &n_early);
+    g->n_early = n_early;
+    return rc;
+}
+
 int sttm_quadtree_merge_batch(int n_videos, const void* const* x, int64_t stride_t, int64_t stride_c, int64_t stride_h, int64_t stride_w,
                               int T, int C, int H, int W, int dtype,
                               float threshold, float temporal_thresh, int root_level, int weighted_avg, int head_dim, int slow_ver,
@@ -608,6 +630,45 @@ int sttm_quadtree_apply(const void* v, int64_t stride_t, int64_t stride_c, int64
 
 // The wait for N': a short busy spin (the counts usually arrive within tens of microseconds), then a yielding poll so that
 // a long kernel queue ahead of this call does not burn a core.
+int sttm_wait_counts_early(const int32_t* counts_host, const uint64_t* early_host, int n_early, int seq, int timeout_us, int32_t* out) {
+    if (!counts_host || !out || (n_early > 0 && !early_host) || n_early > STTM_EARLY_SLOTS) return fail(STTM_ERR_ARG, "bad arguments");
+    const volatile int32_t* flag = counts_host + STTM_CNT_SLOTS - 1;
+    const volatile uint64_t* col = early_host;
+    timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    int have = 0;                         // columns 0 .. have-1 have reported (each word is written once per seq)
+    long long sum = 0;
+    unsigned flags = 0;
+    for (unsigned spins = 0;; ++spins) {
+        while (have < n_early) {
+            const uint64_t w = col[have];
+            if ((uint32_t)(w >> 32) != (uint32_t)seq) break;
+            sum += (long long)(w & 0x0fffffffull);
+            flags |= (unsigned)(w & 0xc0000000ull);
+            ++have;
+        }
+        if (n_early > 0 && have == n_early) {
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            out[0] = (int32_t)sum;
+            out[1] = ((flags & 0x80000000u) ? STTM_OVF_BARRIER_TIMEOUT : 0) | ((flags & 0x40000000u) ? 1 : 0);
+            return STTM_OK;
+        }
+        if (*flag == seq) {
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            out[0] = counts_host[STTM_CNT_OUT];
+            out[1] = counts_host[STTM_CNT_OVERFLOW];
+            return STTM_OK;
+        }
+        __builtin_ia32_pause();
+        if ((spins & 255u) == 255u) {
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            const long long us = (t1.tv_sec - t0.tv_sec) * 1000000ll + (t1.tv_nsec - t0.tv_nsec) / 1000;
+            if (us > timeout_us) return fail(STTM_ERR_LAUNCH, "timed out waiting for the token counts");
+            if (us > 200) sched_yield();
+        }
+    }
+}
+
 int sttm_wait_counts(const int32_t* counts_host, int seq, int timeout_us) {
     if (!counts_host) return fail(STTM_ERR_ARG, "null pointer");
     const volatile int32_t* flag = counts_host + STTM_CNT_SLOTS - 1;

@@ -124,6 +124,7 @@ struct TemporalArgs {
     int32_t* counts;
     int32_t* counts_host;     // optional host-mapped (pinned) mirror of counts, published by the label stage with slot 7 = seq
     int seq;
+    unsigned long long* early_host;   // optional pinned uint64[R]: every column's (seq << 32 | flags | survivors), stored by the column itself
     // outputs
     void* feat_out;
     int32_t* npatch_out;

@@ -523,6 +523,15 @@ __device__ __forceinline__ bool column_labels(const TemporalArgs& a, int r, cons
         unsigned long long* word = reinterpret_cast<unsigned long long*>(a.bar + 2);
         const unsigned long long mine = ((unsigned long long)(ovf > 127 ? 127 : ovf) << 56) | ((unsigned long long)(unsigned)tot[2] << 24) | 1ull;
         (void)__hip_atomic_fetch_add(word, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // early publication (ABI v5): this column's survivors straight into pinned host memory -- one aligned 64-bit store, seq in
+        // the upper half, nothing to order and nothing returned; the host adds the R words up a kernel boundary before the
+        // group-mean kernel's first workgroup could tell it N'
+        if (a.early_host) {
+            const bool timed_out = MODE == COL_FUSED && !alive;
+            const unsigned long long w = ((unsigned long long)(unsigned)a.seq << 32) | (timed_out ? 0x80000000ull : 0ull) |
+                                         ((ovf && !timed_out) ? 0x40000000ull : 0ull) | (unsigned long long)((unsigned)tot[2] & 0x0fffffffu);
+            __hip_atomic_store(a.early_host + r, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         if (tot[0]) atomicAdd(a.counts + STTM_CNT_NODES, tot[0]);
         if (tot[1]) atomicAdd(a.counts + STTM_CNT_LEAFNODES, tot[1]);
         if (tot[3]) atomicAdd(a.counts + STTM_CNT_CANDIDATES, tot[3]);

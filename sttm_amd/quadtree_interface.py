@@ -105,11 +105,15 @@ def _wait(lib, host_row, seq, stream, counts_row):
         host_row.copy_(counts_row, non_blocking=True)  # fallback: classic D2H + stream sync
         stream.synchronize()
     cnt = host_row.tolist()
-    if cnt[_lib.CNT_OVERFLOW] & _lib.OVF_BARRIER_TIMEOUT:
-        raise BarrierTimeout("libsttm_hip: the fused label stage's grid barrier timed out (other streams held the CUs): counts=%s" % cnt)
-    if cnt[_lib.CNT_OVERFLOW]:
-        raise RuntimeError("libsttm_hip: internal list overflow (please report): counts=%s" % cnt)
+    _check_overflow(cnt[_lib.CNT_OVERFLOW], cnt)
     return cnt
+
+
+def _check_overflow(ovf, cnt):
+    if ovf & _lib.OVF_BARRIER_TIMEOUT:
+        raise BarrierTimeout("libsttm_hip: the fused label stage's grid barrier timed out (other streams held the CUs): counts=%s" % (cnt,))
+    if ovf:
+        raise RuntimeError("libsttm_hip: internal list overflow (please report): counts=%s" % (cnt,))
 
 
 class BarrierTimeout(RuntimeError):
@@ -131,58 +135,161 @@ def _retry_without_fused_labels(fn):
     return wrapped
 
 
+class _StreamState:
+    """Everything one (device, stream) needs call after call: the argument block of sttm_quadtree_merge_packed (only the fields
+    that change are rewritten), the pinned landing pad of N' (classic counts + the early per-column words), scratch."""
+    __slots__ = ("args", "args_ptr", "pinned", "host_ptr", "early_ptr", "host_view", "out2", "out2_ptr", "ws", "counts", "key", "lock")
+
+    def __init__(self, dev):
+        # one pinned block: int32[8] classic counts, then uint64[EARLY_SLOTS] early words (8-byte aligned at byte 32)
+        self.pinned = torch.zeros(4 + _lib.EARLY_SLOTS, dtype=torch.int64).pin_memory()
+        self.host_ptr = self.pinned.data_ptr()
+        self.early_ptr = self.host_ptr + 32
+        self.host_view = self.pinned[:4].view(torch.int32)
+        self.args = _lib.MergeArgs()
+        self.args_ptr = ctypes.addressof(self.args)
+        self.args.counts_host = self.host_ptr
+        self.args.early_host = self.early_ptr
+        self.args.stride_c = 1
+        self.out2 = (ctypes.c_int32 * 2)()
+        self.out2_ptr = ctypes.addressof(self.out2)
+        self.ws = None
+        self.counts = None
+        self.key = None
+        self.lock = threading.Lock()
+
+
+_states = _lib.BoundedCache(8)          # (device index, raw stream handle) -> _StreamState
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def _state_for(dev, idx, handle):
+    key = (idx, handle)
+    st = _states.get(key)
+    if st is None:
+        with _seq_lock:
+            st = _states.get(key)
+            if st is None:
+                st = _StreamState(dev)
+                _states[key] = st
+    return st
+
+
 @_retry_without_fused_labels
 def quadtree_merge_raw(x, threshold, temporal_thresh, root_level, weighted_avg, head_dim, slow_ver=False, return_ctx=False,
                        feat_dest=None, events=None):
     """Launch the merge of one video and return the worst-case-sized outputs plus the host counts (only the slots CNT_OUT and
-    CNT_OVERFLOW of the host mirror are published early; the diagnostic counters stay in the device `counts` tensor of the
-    returned context and are complete once the stream has drained).
+    CNT_OVERFLOW are filled in on the host; the diagnostic counters stay in the device `counts` tensor of the returned context
+    and are complete once the stream has drained).
     x: logical [T, C, H, W] CUDA tensor (any strides; channels-last views run zero-copy).
-    events: optional _lib.KernelEvents -- the library records them around its kernels (per-kernel timing)."""
+    events: optional _lib.KernelEvents -- the library records them around its kernels (per-kernel timing).
+
+    Host path (round 3): the device chain of one call is ~80 us and the next call cannot be issued before this one knows N', so
+    every microsecond between "N' arrived" and "next spatial kernel submitted" is device idle time.  Hence: no device context
+    switch when the tensor's device is already current, the raw stream handle instead of a Stream object, one argument block
+    per (device, stream) of which only the changing fields are rewritten, N' read from the early per-column words."""
     if not x.is_cuda:
         raise RuntimeError("sttm_amd runs on the GPU only: the input must be a CUDA (ROCm) tensor; "
                            "there is no CPU fallback")
     if x.dim() != 4:
         raise ValueError("expected a [T, C, H, W] tensor")
-    if x.dtype not in _DTYPE_CODE:
+    dtype = _DTYPE_CODE.get(x.dtype)
+    if dtype is None:
         raise NotImplementedError(f"dtype {x.dtype} is not supported (float32, bfloat16, float16)")
-    lib = _lib.load()
-    T, C, H, W = x.shape
     dev = x.device
-    dtype = _DTYPE_CODE[x.dtype]
-    head_dim = 0 if head_dim is None else int(head_dim)
-    nbytes = _workspace_bytes(lib, T, H, W, C, dtype, root_level)
-    N = T * H * W
-    with torch.cuda.device(dev):
-        stream = torch.cuda.current_stream(dev)
-        guard = _stream_guard((dev, stream.cuda_stream))
-        try:
-            x = _channels_last(x)
-            ws, counts = _scratch(dev, stream, nbytes, 1)
-            if feat_dest is None:
-                feat = torch.empty((N, C), dtype=x.dtype, device=dev)
-            else:
-                # caller-owned destination (fused slice -> merge -> concat): rows [0, N') of it receive the merged features
-                feat = feat_dest
-                if (feat.dim() != 2 or feat.size(1) != C or feat.dtype != x.dtype or feat.device != dev
-                        or not feat.is_contiguous() or feat.data_ptr() % 16):
-                    raise ValueError("feat_dest must be a contiguous, 16-byte aligned [rows, C] tensor of the input's dtype and device")
-            npatch = torch.empty(N, dtype=torch.int32, device=dev)
-            tlbr = torch.empty((N, 5), dtype=torch.int32, device=dev)
-            host = _counts_host(dev, stream.cuda_stream)
-            seq = _next_seq()
-            rc = lib.sttm_quadtree_merge_async(
-                x.data_ptr(), x.stride(0), x.stride(1), x.stride(2), x.stride(3), T, C, H, W, dtype,
-                float(threshold), float(temporal_thresh), int(root_level), int(bool(weighted_avg)), head_dim,
-                int(bool(slow_ver)), ws.data_ptr(), ws.numel(), feat.data_ptr(), npatch.data_ptr(), tlbr.data_ptr(),
-                counts.data_ptr(), host.data_ptr(), seq, events.pointer() if events is not None else None, stream.cuda_stream)
+    idx = dev.index
+    if idx is None or torch.cuda.current_device() != idx:
+        with torch.cuda.device(dev):
+            return _merge_on_current_device(x, dtype, threshold, temporal_thresh, root_level, weighted_avg, head_dim, slow_ver,
+                                            return_ctx, feat_dest, events)
+    return _merge_on_current_device(x, dtype, threshold, temporal_thresh, root_level, weighted_avg, head_dim, slow_ver,
+                                    return_ctx, feat_dest, events)
+
+
+def _merge_on_current_device(x, dtype, threshold, temporal_thresh, root_level, weighted_avg, head_dim, slow_ver, return_ctx,
+                             feat_dest, events):
+    lib = _lib.load()
+    dev = x.device
+    idx = torch.cuda.current_device()
+    handle = _raw_stream(idx) if _raw_stream is not None else torch.cuda.current_stream(dev).cuda_stream
+    st = _state_for(dev, idx, handle)
+    lock = st.lock
+    if not lock.acquire(False) and not lock.acquire(timeout=_GUARD_TIMEOUT_S):
+        # (two host threads on the SAME stream share its scratch and landing pad: their calls are serialised)
+        raise RuntimeError("sttm_amd: waited %.0f s for another host thread inside a merge call on this same stream "
+                           "(give every thread its own torch.cuda.Stream: the scratch and the pinned counts are per stream)"
+                           % _GUARD_TIMEOUT_S)
+    try:
+        T, C, H, W = x.shape
+        sT, sC, sH, sW = x.stride()
+        ptr = x.data_ptr()
+        # the production layout is a channels-last VIEW (stride_c == 1); anything else -- or a frame spanning >= 2 GiB, which
+        # the spatial kernel's 32-bit frame offsets cannot address -- gets one transposing copy on the current stream
+        if sC != 1 or (ptr & 15) or ((H - 1) * sH + (W - 1) * sW + C) * x.element_size() >= 2 ** 31:
+            x = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+            sT, sC, sH, sW = x.stride()
+            ptr = x.data_ptr()
+        head = 0 if head_dim is None else int(head_dim)
+        N = T * H * W
+        a = st.args
+        key = (T, C, H, W, dtype, sT, sH, sW, threshold, temporal_thresh, root_level, weighted_avg, head, slow_ver)
+        if key != st.key:
+            nbytes = _workspace_bytes(lib, T, H, W, C, dtype, root_level)
+            if st.ws is None or st.ws.numel() < nbytes:
+                st.ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                st.counts = torch.empty((16, _lib.CNT_SLOTS), dtype=torch.int32, device=dev)
+            a.stride_t, a.stride_h, a.stride_w = sT, sH, sW
+            a.T, a.C, a.H, a.W, a.dtype = T, C, H, W, dtype
+            a.threshold, a.temporal_thresh = float(threshold), float(temporal_thresh)
+            a.root_level, a.weighted_avg, a.head_dim, a.slow_ver = int(root_level), int(bool(weighted_avg)), head, int(bool(slow_ver))
+            a.workspace, a.workspace_bytes = st.ws.data_ptr(), st.ws.numel()
+            a.counts = st.counts.data_ptr()
+            a.stream = handle
+            st.key = key
+        if feat_dest is None:
+            feat = torch.empty((N, C), dtype=x.dtype, device=dev)
+        else:
+            # caller-owned destination (fused slice -> merge -> concat): rows [0, N') of it receive the merged features
+            feat = feat_dest
+            if (feat.dim() != 2 or feat.size(1) != C or feat.dtype != x.dtype or feat.device != dev
+                    or not feat.is_contiguous() or feat.data_ptr() % 16):
+                raise ValueError("feat_dest must be a contiguous, 16-byte aligned [rows, C] tensor of the input's dtype and device")
+        npatch = torch.empty(N, dtype=torch.int32, device=dev)
+        tlbr = torch.empty((N, 5), dtype=torch.int32, device=dev)
+        seq = _next_seq()
+        a.x, a.feat_out, a.npatch_out, a.tlbr_out, a.seq = ptr, feat.data_ptr(), npatch.data_ptr(), tlbr.data_ptr(), seq
+        a.events = events.pointer() if events is not None else None
+        rc = lib.sttm_quadtree_merge_packed(st.args_ptr)
+        if rc < 0:
+            st.key = None
             _lib.raise_for(rc)
-            cnt = _wait(lib, host[0], seq, stream, counts[0])
-        finally:
-            guard.release()
+        # Output sizes are data dependent, so the host must learn N' -- but only N': every column of the label stage reports its
+        # survivors into pinned memory as its last action (fallback: the group-mean kernel's first workgroup publishes the counts)
+        # and we wait on that, returning while the feature gather is still running.
+        if lib.sttm_wait_counts_early(st.host_ptr, st.early_ptr, a.n_early, seq, 2_000_000, st.out2_ptr) != 0:
+            stream = torch.cuda.current_stream(dev)
+            st.host_view.copy_(st.counts[0], non_blocking=True)  # fallback: classic D2H + stream sync
+            stream.synchronize()
+            h = st.host_view.tolist()
+            st.out2[0], st.out2[1] = h[_lib.CNT_OUT], h[_lib.CNT_OVERFLOW]
+        n_out, ovf = st.out2[0], st.out2[1]
+        cnt = [0] * _lib.CNT_SLOTS
+        cnt[_lib.CNT_OUT], cnt[_lib.CNT_OVERFLOW] = n_out, ovf
+        if ovf:
+            _check_overflow(ovf, cnt)
+    finally:
+        lock.release()
     if return_ctx:
-        return feat, npatch, tlbr, cnt, (x, ws, counts, dtype, stream)
+        return feat, npatch, tlbr, cnt, (x, st.ws, st.counts, dtype, _StreamHandle(handle, dev))
     return feat, npatch, tlbr, cnt
+
+
+class _StreamHandle:
+    """What the context tuple of quadtree_merge_raw carries as its stream: the raw handle (all the C ABI needs)."""
+    __slots__ = ("cuda_stream", "device")
+
+    def __init__(self, handle, device):
+        self.cuda_stream, self.device = handle, device
 
 
 def _apply_side_tensor(v, ctx, root_level, sum_mode):

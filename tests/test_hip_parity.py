@@ -248,9 +248,10 @@ def test_same_stream_from_two_threads_is_serialised_not_raced():
     from sttm_amd.synth import synth_video
     dev = _dev()
     x = synth_video(8, 64, 14, 14, seed=3).to(dev)
-    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
     ref = get_quadtree_features(x, 0.85, 0.55, 1)
-    lock = QI._stream_guard(key)                 # stand-in for "another thread is inside the call"
+    # stand-in for "another thread is inside the call": hold the lock of this (device, stream)'s state
+    lock = QI._state_for(dev, dev.index, torch.cuda.current_stream(dev).cuda_stream).lock
+    assert lock.acquire(False)
     out, errs = [], []
 
     def other():
@@ -274,7 +275,7 @@ def test_same_stream_from_two_threads_is_serialised_not_raced():
         with torch.cuda.stream(torch.cuda.Stream(dev)):
             get_quadtree_features(x, 0.85, 0.55, 1)
     torch.cuda.synchronize()
-    assert len(QI._stream_locks) <= 4 * max(QI._ws_cache.limit, QI._pinned_counts.limit) + 1
+    assert len(QI._states) <= QI._states.limit           # per-stream state (scratch, pinned landing pad, lock) is bounded
 
 
 def test_batched_extension_equals_per_video_calls():

@@ -14,21 +14,21 @@ for x in pool:
 torch.cuda.synchronize()
 lib = _lib.load()
 stamps = {"launch": 0.0, "wait": 0.0}
-orig_launch, orig_wait = lib.sttm_quadtree_merge_async, qi._wait
+orig_launch, orig_wait = lib.sttm_quadtree_merge_packed, lib.sttm_wait_counts_early
 pc = time.perf_counter
 
-
-def timed_wait(*a):
-    t0 = pc(); r = orig_wait(*a); stamps["wait"] += pc() - t0
-    return r
 
 
 class L:
     def __getattr__(self, k):
         return getattr(lib, k)
 
-    def sttm_quadtree_merge_async(self, *a):
+    def sttm_quadtree_merge_packed(self, *a):
         t0 = pc(); r = orig_launch(*a); stamps["launch"] += pc() - t0
+        return r
+
+    def sttm_wait_counts_early(self, *a):
+        t0 = pc(); r = orig_wait(*a); stamps["wait"] += pc() - t0
         return r
 
 
@@ -37,7 +37,6 @@ torch.cuda.synchronize(); t0 = pc()
 for i in range(n):
     get_quadtree_features(pool[i % 8], 0.85, 0.55, 1)
 torch.cuda.synchronize(); base = (pc() - t0) / n
-qi._wait = timed_wait
 qi._lib = type("M", (), {k: getattr(_lib, k) for k in dir(_lib)})
 qi._lib.load = staticmethod(lambda: L())
 torch.cuda.synchronize(); t0 = pc()
