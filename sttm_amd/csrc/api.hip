@@ -24,7 +24,7 @@ int fail(int code, const char* fmt, ...) {
 // Tuning / test switches: defaults from STTM_<KEY> environment variables, read ONCE; sttm_configure overrides them.
 // None of them changes results.
 struct Config {
-    int pairs_seg, pairs_nt, pairs_var, gm_var, gm_split, label_nt, vec16, vec32, fold_kb, fold_labels, no_fuse, force_gmem_labels, tome_split;
+    int pairs_seg, pairs_nt, pairs_var, gm_var, no_dense, gm_split, label_nt, vec16, vec32, fold_kb, fold_labels, no_fuse, force_gmem_labels, tome_split;
 };
 int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
@@ -37,6 +37,7 @@ Config& config() {
         d.pairs_nt = env_int("STTM_PAIRS_NT", 0);
         d.pairs_var = env_int("STTM_PAIRS_VAR", 0);
         d.gm_var = env_int("STTM_GM_VAR", 0);
+        d.no_dense = env_int("STTM_NO_DENSE", 0);
         d.gm_split = env_int("STTM_GM_SPLIT", 0);
         d.label_nt = env_int("STTM_LABEL_NT", 1024);
         d.vec16 = env_int("STTM_VEC16", 0);
@@ -407,6 +408,7 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
     ta.max_slots = p.max_slots;
     ta.force_gmem = cfg.force_gmem_labels ? 1 : 0;
     ta.no_fuse = cfg.no_fuse ? 1 : 0;
+    ta.no_dense = cfg.no_dense ? 1 : 0;
     ta.want_fold = cfg.fold_labels ? 1 : 0;
     ta.fold_kb = cfg.fold_kb > 0 ? cfg.fold_kb : 64;
     ta.S = b.S; ta.xrows = dense ? x[0] : nullptr; ta.meta = b.meta; ta.inrm = b.inrm; ta.rc_list = b.rc_list; ta.rc_stride = p.rc_stride;
@@ -486,7 +488,7 @@ int sttm_configure(const char* key, int value) {
     if (!key) return fail(STTM_ERR_ARG, "null key");
     Config& c = config();
     struct { const char* name; int* slot; } keys[] = {
-        {"pairs_seg", &c.pairs_seg}, {"pairs_nt", &c.pairs_nt}, {"pairs_var", &c.pairs_var}, {"gm_var", &c.gm_var}, {"gm_split", &c.gm_split}, {"label_nt", &c.label_nt},
+        {"pairs_seg", &c.pairs_seg}, {"pairs_nt", &c.pairs_nt}, {"pairs_var", &c.pairs_var}, {"gm_var", &c.gm_var}, {"no_dense", &c.no_dense}, {"gm_split", &c.gm_split}, {"label_nt", &c.label_nt},
         {"vec16", &c.vec16}, {"vec32", &c.vec32}, {"fold_kb", &c.fold_kb}, {"fold_labels", &c.fold_labels}, {"no_fuse", &c.no_fuse}, {"tome_split", &c.tome_split},
         {"force_gmem_labels", &c.force_gmem_labels},
     };

@@ -110,6 +110,7 @@ struct TemporalArgs {
     int32_t* col_arrive;      // [R] arrivals of a column's pair workgroups (zeroed by the spatial kernel)
     int32_t* frame_cnt;       // [T] survivors per frame (zeroed by the spatial kernel)
     int32_t* bar;             // [8] overflow flag, N' word, grid-barrier word (zeroed by the spatial kernel)
+    int no_dense;             // option: never use the uncompacted (slot-indexed) form of the column label stage
     int no_fuse, want_fold;   // options: two-launch label path / label stage inside the pair kernel (opt-in)
     int fold_kb;              // LDS budget (KB) of a pair workgroup when the label stage is folded in
     int fold_labels;          // the last pair workgroup of a column to arrive runs that column's label stage

@@ -292,8 +292,14 @@ __device__ __forceinline__ void publish_counts(const TemporalArgs& a, int n_out,
 //        COL_FUSED : probe -> grid barrier -> (replay only if K is smaller than this column's own count) -> results
 // Results: lab_row / gcnt of the column's active nodes (the spatial kernel wrote the singleton defaults), the column's
 // survivors added to frame_cnt[t], bookkeeping counters, and the column's share of N' (+ overflow events) in one 64-bit word.
-template <bool GMEM, int MODE>
+//   DENSE (LDS only, columns of at most kDenseSlots slots -- the 128-frame headline has 2048): ids are the column's slots
+//        themselves.  The bitmask only says which slots take part (results are written for those); the prefix over the bit
+//        counts, the id table and the raw-pair staging with its conversion pass are gone (round 3: 1.8 of the label kernel's
+//        12 us went into the compaction of ~500 ids that fit LDS uncompacted).  Slots without a node keep label == slot.
+constexpr int kDenseSlots = 8192;
+template <bool GMEM, int MODE, bool DENSE = false>
 __device__ __forceinline__ bool column_labels(const TemporalArgs& a, int r, const Column& col, const ColArrays& arr, ColShared* sh) {
+    static_assert(!(GMEM && DENSE), "the dense form lives in LDS");
     const int R = a.R;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nwave = nt >> 6;
@@ -324,13 +330,14 @@ __device__ __forceinline__ bool column_labels(const TemporalArgs& a, int r, cons
         auto take = [&](int t, int packed, int pos) {
             const unsigned w = (unsigned)packed;
             const int sd = t * col.A + (int)(w >> 16), ss = (t + 1) * col.A + (int)(w & 0xffffu);
-            if (pos < arr.cap) { cst<GMEM>(rawd + pos, sd); cst<GMEM>(raws + pos, ss); }
+            if constexpr (DENSE) { if (pos < arr.cap) edge_put<GMEM>(edges, pos, sd, ss); }
+            else if (pos < arr.cap) { cst<GMEM>(rawd + pos, sd); cst<GMEM>(raws + pos, ss); }
             caor<GMEM>(bits + (sd >> 5), (int)(1u << (sd & 31)));
             caor<GMEM>(bits + (ss >> 5), (int)(1u << (ss & 31)));
         };
         // ONE round trip: the length of every pair's list together with its first HEAD entries (a list holds two edges on
         // average; entries past the length are stale).  The thread that reads entry 0 of a longer list walks the rest.
-        constexpr int HEAD = 8, PER = 2;
+        constexpr int HEAD = 16, PER = 2;           // (16: a list longer than the prefetched head is walked with dependent loads -- rare now)
         const int total = nf * HEAD;
         for (int j0 = 0; j0 < total; j0 += PER * nt) {
             int val[PER], tt[PER], cn[PER];
@@ -373,6 +380,12 @@ __device__ __forceinline__ bool column_labels(const TemporalArgs& a, int r, cons
         col_sync<GMEM>();
         E = sh->ecount;
         STTM_LBL_TICK(1);
+        if constexpr (DENSE) {
+            if (E > arr.cap) return false;
+            nact = slots;
+            for (int s2 = tid; s2 < slots; s2 += nt) { rep[s2] = s2; rep2[s2] = s2; }
+            col_sync<GMEM>();
+        } else {
         // ---- order-preserving compact ids: prefix of the bit counts ------------------------------------------------------
         {
             const int per = (W + nt - 1) / nt;
@@ -402,6 +415,7 @@ __device__ __forceinline__ bool column_labels(const TemporalArgs& a, int r, cons
             }
         }
         col_sync<GMEM>();
+        }
         STTM_LBL_TICK(2);
     }
 
@@ -478,12 +492,15 @@ __device__ __forceinline__ bool column_labels(const TemporalArgs& a, int r, cons
             col_sync<GMEM>();
             // results of the active nodes (plain stores: the consumer is the next kernel); merged-away nodes per frame
             for (int i = tid; i < nact; i += nt) {
-                const int s = cld<GMEM>(cslot + i), rr = cld<GMEM>(rep + i);
+                if constexpr (DENSE) {
+                    if (!(((unsigned)bits[i >> 5] >> (i & 31)) & 1u)) continue;       // no node with a kept edge starts at this slot
+                }
+                const int s = DENSE ? i : cld<GMEM>(cslot + i), rr = cld<GMEM>(rep + i);
                 const int row = slot_to_row(a, col, s);
                 if (rr == i) {
                     a.gcnt[row] = cld<GMEM>(rep2 + i);
                 } else {
-                    a.lab_row[row] = slot_to_row(a, col, cld<GMEM>(cslot + rr));
+                    a.lab_row[row] = slot_to_row(a, col, DENSE ? rr : cld<GMEM>(cslot + rr));
                     a.gcnt[row] = 0;
                     caadd<GMEM>(dec + slot_frame(col, s), 1);
                 }
@@ -580,6 +597,10 @@ __device__ __forceinline__ void column_labels_any(const TemporalArgs& a, const L
     ColShared* sh;
     const ColArrays lds = col_arrays_lds(smem, cap > 0 ? cap : 0, cap > 0 ? col.slots : 0, cap > 0 ? a.T : 0, &sh);
     if (cap > 0 && !a.force_gmem) {
+        if (col.slots <= kDenseSlots && col.slots <= cap && !a.no_dense) {
+            if (column_labels<false, MODE, true>(a, r, col, lds, sh)) return;       // (false: more kept edges than room -- cannot happen
+            __syncthreads();                                                       //  while cap >= slots; the compact form decides)
+        }
         if (column_labels<false, MODE>(a, r, col, lds, sh)) return;
         __syncthreads();
     }
