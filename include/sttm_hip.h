@@ -183,8 +183,8 @@ int sttm_quadtree_merge_batch(int n_videos, const void* const* x, int64_t stride
  *   "fold_kb"     LDS budget (KB) per pair workgroup when the label stage runs inside the pair kernel (default 64)
  *   "fold_labels" 1: run a column's label stage inside the pair kernel, in the column's last workgroup to finish (default 0:
  *                 stand-alone label kernel; the folded form is no faster on MI355X and is kept for experiments)
- *   "pairs_var"   9: the general pair kernel instead of the lean 256-thread form;  "gm_var" 9: first form of the group-mean kernel
- *   "no_dense"    1: column label stage always on compact ids (default: columns of <= 8192 slots work on their slots directly)
+ *   "pairs_var"   9: the general pair kernel instead of the lean 256-thread form (tests / A-B)
+ *   "no_dense"    1: column label stage always on compact ids (default: columns of <= 4096 slots work on their slots directly)
  *   "no_fuse"     1: stand-alone label stage as two launches (no in-kernel grid barrier)
  *   "force_gmem_labels"  1: label stage on global scratch instead of LDS (the path of columns too large for LDS)
  *   "tome_split"  ToMe match kernel for float32 inputs.  1 (default): unit rows as two fp16 planes (h + l of 4096 v, residual

@@ -24,7 +24,7 @@ int fail(int code, const char* fmt, ...) {
 // Tuning / test switches: defaults from STTM_<KEY> environment variables, read ONCE; sttm_configure overrides them.
 // None of them changes results.
 struct Config {
-    int pairs_seg, pairs_nt, pairs_var, gm_var, no_dense, gm_split, label_nt, vec16, vec32, fold_kb, fold_labels, no_fuse, force_gmem_labels, tome_split;
+    int pairs_seg, pairs_nt, pairs_var, no_dense, gm_split, label_nt, vec16, vec32, fold_kb, fold_labels, no_fuse, force_gmem_labels, tome_split;
 };
 int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
@@ -36,7 +36,6 @@ Config& config() {
         d.pairs_seg = env_int("STTM_PAIRS_SEG", 0);
         d.pairs_nt = env_int("STTM_PAIRS_NT", 0);
         d.pairs_var = env_int("STTM_PAIRS_VAR", 0);
-        d.gm_var = env_int("STTM_GM_VAR", 0);
         d.no_dense = env_int("STTM_NO_DENSE", 0);
         d.gm_split = env_int("STTM_GM_SPLIT", 0);
         d.label_nt = env_int("STTM_LABEL_NT", 1024);
@@ -416,7 +415,7 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
     ta.ecap_magic = 0xffffffffu / (unsigned)p.ecap + 1u;
     ta.col_mask = b.col_mask; ta.col_arrive = b.col_arrive; ta.frame_cnt = b.frame_cnt; ta.bar = b.bar;
     ta.colscratch = b.colscratch;
-    ta.gm_split = gm_split_for(T); ta.gm_var = cfg.gm_var; ta.lab_row = b.lab_row; ta.gcnt = b.gcnt; ta.cgeo = b.cgeo;
+    ta.gm_split = gm_split_for(T); ta.lab_row = b.lab_row; ta.gcnt = b.gcnt; ta.cgeo = b.cgeo;
     ta.counts = counts;
     ta.counts_host = counts_host; ta.seq = seq;
     // every column reports its survivors to the host itself (single video, a slot per column)
@@ -488,7 +487,7 @@ int sttm_configure(const char* key, int value) {
     if (!key) return fail(STTM_ERR_ARG, "null key");
     Config& c = config();
     struct { const char* name; int* slot; } keys[] = {
-        {"pairs_seg", &c.pairs_seg}, {"pairs_nt", &c.pairs_nt}, {"pairs_var", &c.pairs_var}, {"gm_var", &c.gm_var}, {"no_dense", &c.no_dense}, {"gm_split", &c.gm_split}, {"label_nt", &c.label_nt},
+        {"pairs_seg", &c.pairs_seg}, {"pairs_nt", &c.pairs_nt}, {"pairs_var", &c.pairs_var}, {"no_dense", &c.no_dense}, {"gm_split", &c.gm_split}, {"label_nt", &c.label_nt},
         {"vec16", &c.vec16}, {"vec32", &c.vec32}, {"fold_kb", &c.fold_kb}, {"fold_labels", &c.fold_labels}, {"no_fuse", &c.no_fuse}, {"tome_split", &c.tome_split},
         {"force_gmem_labels", &c.force_gmem_labels},
     };
@@ -619,7 +618,7 @@ int sttm_quadtree_apply(const void* v, int64_t stride_t, int64_t stride_c, int64
     ta.weighted_avg = sum_mode ? 1 : 0;
     ta.S = b.S; ta.xrows = dense ? v : nullptr;
     ta.frame_cnt = b.frame_cnt; ta.lab_row = b.lab_row; ta.gcnt = b.gcnt; ta.cgeo = b.cgeo;
-    ta.meta = b.meta; ta.gm_split = gm_split_for(T); ta.gm_var = config().gm_var;
+    ta.meta = b.meta; ta.gm_split = gm_split_for(T);
     ta.counts = const_cast<int32_t*>(counts);
     ta.feat_out = out;
     sttm::BatchPtrs bp;

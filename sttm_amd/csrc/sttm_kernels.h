@@ -102,7 +102,7 @@ struct TemporalArgs {
     unsigned ecap_magic;      // ceil(2^32 / ecap): j / ecap for j < (T-1) * ecap
     int pairs_seg;            // k_pairs: consecutive frame pairs of one root cell per workgroup
     int pairs_nt;             // k_pairs block size (power of two, 64 .. 1024)
-    int pairs_var;            // EXPERIMENT: register / unroll variant of the 256-thread pair kernel
+    int pairs_var;            // 9: the general pair kernel (k_pairs) also for the default shape (tests / A-B)
     float* edge_sim;          // [R][T-1][ecap] similarity of each kept edge (slow_ver only, else null)
     int32_t* edge_cnt;        // [R][T-1]
     int32_t* cand_cnt;        // [R][T-1]
@@ -118,7 +118,6 @@ struct TemporalArgs {
     int label_nt;             // threads per column workgroup of the stand-alone label kernels
     int32_t* colscratch;      // label arrays of columns that do not fit LDS
     int gm_split;             // group-mean workgroups per frame
-    int gm_var;               // EXPERIMENT: 0 = k_group_mean, > 0 = k_group_mean2 with this register bound
     int32_t* lab_row;         // [T*H*W] by origin row: origin row of the node's representative (-1: no node starts here)
     int32_t* gcnt;            // [T*H*W] by origin row: members of the group this node represents; 0 = not a survivor
     const uint32_t* cgeo;     // [H*W] root-cell geometry of every leaf position (written by the spatial kernel)

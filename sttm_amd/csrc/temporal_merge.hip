@@ -292,11 +292,11 @@ __device__ __forceinline__ void publish_counts(const TemporalArgs& a, int n_out,
 //        COL_FUSED : probe -> grid barrier -> (replay only if K is smaller than this column's own count) -> results
 // Results: lab_row / gcnt of the column's active nodes (the spatial kernel wrote the singleton defaults), the column's
 // survivors added to frame_cnt[t], bookkeeping counters, and the column's share of N' (+ overflow events) in one 64-bit word.
-//   DENSE (LDS only, columns of at most kDenseSlots slots -- the 128-frame headline has 2048): ids are the column's slots
+//   DENSE (LDS only, columns of at most kDenseSlots slots -- the 128-frame headline has 2048; measured slower than the compact form at 8192): ids are the column's slots
 //        themselves.  The bitmask only says which slots take part (results are written for those); the prefix over the bit
 //        counts, the id table and the raw-pair staging with its conversion pass are gone (round 3: 1.8 of the label kernel's
 //        12 us went into the compaction of ~500 ids that fit LDS uncompacted).  Slots without a node keep label == slot.
-constexpr int kDenseSlots = 8192;
+constexpr int kDenseSlots = 4096;
 template <bool GMEM, int MODE, bool DENSE = false>
 __device__ __forceinline__ bool column_labels(const TemporalArgs& a, int r, const Column& col, const ColArrays& arr, ColShared* sh) {
     static_assert(!(GMEM && DENSE), "the dense form lives in LDS");
@@ -532,11 +532,18 @@ __device__ __forceinline__ bool column_labels(const TemporalArgs& a, int r, cons
     }
     if (lane == 0) { sh->part[0][wave] = nodes; sh->part[1][wave] = leafnodes; sh->part[2][wave] = survivors; sh->part[3][wave] = cand; }
     col_sync<GMEM>();
-    if (tid == 0) {
-        int tot[4] = {0, 0, 0, 0};
-        for (int w = 0; w < nwave; ++w)
+    // the first wave adds the per-wave partials up: lane (k, w) fetches one, four butterfly steps over w (thread 0 alone walked
+    // the 64 LDS words one dependent read after the other: ~1 us at the very end of every column)
+    int tot[4] = {0, 0, 0, 0};
+    if (wave == 0) {
+        const int k = lane >> 4, w = lane & 15;
+        int v = w < nwave ? sh->part[k][w] : 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) tot[k] += sh->part[k][w];
+        for (int d = 8; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) tot[kk] = __shfl(v, kk * 16, 64);
+    }
+    if (tid == 0) {
         unsigned long long* word = reinterpret_cast<unsigned long long*>(a.bar + 2);
         const unsigned long long mine = ((unsigned long long)(ovf > 127 ? 127 : ovf) << 56) | ((unsigned long long)(unsigned)tot[2] << 24) | 1ull;
         (void)__hip_atomic_fetch_add(word, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1020,152 +1027,10 @@ template <> __device__ __forceinline__ float round_to<float>(float f) { return f
 template <> __device__ __forceinline__ float round_to<bf16_t>(float f) { return bf16_bits_to_float(float_to_bf16_bits(f)); }
 template <> __device__ __forceinline__ float round_to<f16_t>(float f) { return f16_bits_to_float(float_to_f16_bits(f)); }
 
-template <typename T, int VEC>
-__global__ void __launch_bounds__(256, TypeInfo<T>::lowp ? 6 : 8) k_group_mean(const TemporalArgs a0, const BatchPtrs bp) {
-    TemporalArgs a = a0;
-    rebase(a, bp, blockIdx.y);
-    // Workgroup (t, s): `gm_split` workgroups share frame t.  Every wave scans the frame's H*W origin slots (one ballot
-    // per 64 slots gives each survivor its rank inside the frame; rows of earlier frames are the sum of frame_cnt before it) and takes
-    // the survivors whose in-frame rank is congruent to its id, so the output order is (frame, y1, x1) with no rank pass.
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
-    const int S = a.gm_split, t = blockIdx.x / S, s = blockIdx.x - t * S;
-    const int HW = a.H * a.W;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && a.bar) {     // (a.bar is null when this kernel only re-merges another tensor: sttm_quadtree_apply)
-        // the label stage left (overflow << 56 | N' << 24 | columns) in one word; complete at this kernel boundary
-        const unsigned long long all = __hip_atomic_load(reinterpret_cast<unsigned long long*>(a.bar + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int timed_out = (ld_agent(a.bar + 1) & 2) ? STTM_OVF_BARRIER_TIMEOUT : 0;     // the fused label stage's grid barrier gave up
-        int ovf = (int)(all >> 56);
-        if (ovf >= STTM_OVF_BARRIER_TIMEOUT) ovf = STTM_OVF_BARRIER_TIMEOUT - 1;
-        publish_counts(a, (int)((all >> 24) & 0xffffffffull), ovf | timed_out);
-    }
-    const int stride = S * nwave, me = s * nwave + wave;
-    // output rows before this frame: every wave sums frame_cnt[0..t) for itself (no LDS, no workgroup barrier)
-    int row0 = 0;
-    for (int f = lane; f < t; f += 64) row0 += a.frame_cnt[f];
-    int j0 = 0;
-    bool row0_done = false;
-    constexpr int NB = 4;                                       // 64-slot chunks whose metadata is loaded together
-    constexpr int U = TypeInfo<T>::lowp ? 4 : 2;                // chunks of a row in flight per lane
-    constexpr int CH = U * 64 * VEC;
-    for (int base = 0; base < HW; base += 64 * NB) {
-        int cnt[NB];
-        uint32_t meta[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {                          // independent loads, one round trip
-            const int p = base + b * 64 + lane;
-            const bool in = p < HW;
-            const int origin = t * HW + (in ? p : 0);
-            cnt[b] = in ? a.gcnt[origin] : 0;
-            meta[b] = a.meta[origin];
-        }
-        if (!row0_done) { row0 = wave_sum_int(row0); row0_done = true; }      // after the metadata loads were issued
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const unsigned long long m = __ballot(cnt[b] > 0);
-            if (m == 0ull) continue;
-            const int j = j0 + __popcll(m & ((1ull << lane) - 1ull));
-            unsigned long long sel = __ballot(cnt[b] > 0 && (j & (stride - 1)) == me);     // stride is a power of two
-            while (sel) {
-                const int l = __ffsll((long long)sel) - 1;
-                sel &= sel - 1ull;
-                const int p = base + b * 64 + l;
-                const int row = row0 + j0 + __popcll(m & ((1ull << l) - 1ull));
-                int n = __builtin_amdgcn_readlane(cnt[b], l);
-#ifdef STTM_DEV
-                if (a.dev.k5_mode == 1) n = 1;
-#endif
-                const uint32_t mt = (uint32_t)__builtin_amdgcn_readlane((int)meta[b], l);
-                const int origin = t * HW + p;
-                const int y1 = p / a.W, x1 = p - y1 * a.W;
-                const int y2 = (int)(mt >> 16), x2 = (int)(mt & 0xffff);
-                const int own_area = (y2 - y1) * (x2 - x1);
-                const void* s0 = (own_area == 1 && a.xrows) ? a.xrows : a.S;          // 1x1 nodes were not copied out of x
-                // members of a multi-node group live in the survivor's column, at slots after its own
-                Column col;
-                int slot0 = 0;
-                if (n > 1) {
-                    col = column_from_geo(a, a.cgeo[p]);              // one wave-uniform load instead of a walk over the level table
-                    slot0 = t * col.A + (y1 - col.Y1) * col.aw + (x1 - col.X1);
-                }
-                int patches = own_area;
-                for (int cb0 = 0; cb0 < a.C; cb0 += CH) {
-                    // U chunks of the row in flight per lane (wide rows would otherwise be a chain of load -> store round trips);
-                    // per element the members are still added in ascending order, one rounding per add
-                    Pack<T, VEC> acc[U];
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const int c0 = cb0 + (u * 64 + lane) * VEC;
-                        if (c0 < a.C) acc[u] = load_pack<T, VEC>(s0, (int64_t)origin * a.C + c0); else acc[u].zero();
-                    }
-                    if (n > 1) {
-                        int found = 0;
-                        for (int sb = slot0 + 1; found < n - 1 && sb < col.slots; sb += 64) {
-                            const int sl = sb + lane;
-                            const int mrow = sl < col.slots ? slot_to_row(a, col, sl) : -1;
-                            // label and box of every scanned slot in the same round trip (the box is only needed for hits)
-                            const int lab = mrow >= 0 ? a.lab_row[mrow] : -1;
-                            const uint32_t q = mrow >= 0 ? a.meta[mrow] : 0u;
-                            const bool hit = lab == origin;
-                            unsigned long long mm = __ballot(hit);
-                            if (mm == 0ull) continue;
-                            int ar = 0;
-                            if (hit) {
-                                const int rem = mrow - slot_frame(col, sl) * HW;
-                                const int my1 = rem / a.W, mx1 = rem - my1 * a.W;
-                                ar = ((int)(q >> 16) - my1) * ((int)(q & 0xffff) - mx1);
-                            }
-                            while (mm) {
-                                const int k = __ffsll((long long)mm) - 1;
-                                mm &= mm - 1ull;
-                                const int mr = __builtin_amdgcn_readlane(mrow, k), ak = __builtin_amdgcn_readlane(ar, k);
-                                const void* sm = (ak == 1 && a.xrows) ? a.xrows : a.S;
-                                const int64_t mbase = (int64_t)mr * a.C;
-                                Pack<T, VEC> q[U];
-#pragma unroll
-                                for (int u = 0; u < U; ++u) {
-                                    const int c0 = cb0 + (u * 64 + lane) * VEC;
-                                    if (c0 < a.C) q[u] = load_pack<T, VEC>(sm, mbase + c0); else q[u].zero();
-                                }
-#pragma unroll
-                                for (int u = 0; u < U; ++u) {
-                                    const Pack<T, VEC> prev = acc[u];
-                                    pack_fill(acc[u], [&](int e) { return prev.get(e) + q[u].get(e); });
-                                }
-                                ++found;
-                                if (cb0 == 0) patches += ak;
-                            }
-                        }
-                    }
-                    const bool divide = a.weighted_avg || n > 1;
-                    if (divide) {
-                        const float den = round_to<T>(a.weighted_avg ? (float)patches : (float)n);
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            const Pack<T, VEC> prev = acc[u];
-                            pack_fill(acc[u], [&](int e) { return prev.get(e) / den; });
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const int c0 = cb0 + (u * 64 + lane) * VEC;
-                        if (c0 < a.C) store_pack_stream<T, VEC>(a.feat_out, (int64_t)row * a.C + c0, acc[u]);
-                    }
-                }
-                if (a.npatch_out && lane == 0) {
-                    a.npatch_out[row] = patches;
-                    int32_t* o = a.tlbr_out + (int64_t)row * 5;
-                    o[0] = t; o[1] = y1; o[2] = x1; o[3] = y2; o[4] = x2;
-                }
-            }
-            j0 += __popcll(m);
-        }
-    }
-}
-
-
 // ---------------------------------------------------------------------------------------------------
-// K5, round-3 form (k_group_mean2).  Same work split as k_group_mean -- workgroup (t, s), every wave ranks the survivors of
-// frame t and takes the ranks congruent to its id -- rebuilt around what the floor probe (tools/micro/floor_probe.hip) showed:
+// K5 (round-3 form).  Workgroup (t, s): `gm_split` workgroups share frame t; every wave ranks the survivors of frame t (one
+// ballot per 64 origin slots) and takes the ranks congruent to its id, so the output order is (frame, y1, x1) with no rank pass.
+// Built around what the floor probe (tools/micro/floor_probe.hip) showed:
 // a two-stage gather of 11.2 k rows of 4 KB runs in 14.6 us when the loads of a stage are all in flight together, while the
 // first form spent 22 us: its frame_cnt prefix loop, its bounds branches around the metadata loads and the column geometry of
 // a group survivor each became a round trip of its own.  Here
@@ -1205,7 +1070,7 @@ __device__ __forceinline__ void store_pack_buf(__amdgpu_buffer_rsrc_t rs, uint32
 struct GmRow { int p, out, n; uint32_t mt, geo; };       // wave-uniform: slot in the frame, output row, group size, box, column geometry
 
 template <typename T, int VEC, int OCC>
-__global__ void __launch_bounds__(256, OCC) k_group_mean2(const TemporalArgs a0, const BatchPtrs bp) {
+__global__ void __launch_bounds__(256, OCC) k_group_mean(const TemporalArgs a0, const BatchPtrs bp) {
     TemporalArgs a = a0;
     rebase(a, bp, blockIdx.y);
     constexpr int eb = TypeInfo<T>::bytes;
@@ -1365,19 +1230,7 @@ __global__ void __launch_bounds__(256, OCC) k_group_mean2(const TemporalArgs a0,
 
 hipError_t launch_group_mean(const TemporalArgs& a, const BatchPtrs& bp, int n_videos, hipStream_t stream) {
     const int grid = a.T * a.gm_split;
-    if (a.gm_var != 9) {          // gm_var = 9 selects the first form of the kernel
-#define STTM_LAUNCH_GM2(TT, VV) hipLaunchKernelGGL((k_group_mean2<TT, VV, 6>), dim3(grid, n_videos), dim3(256), 0, stream, a, bp)
-        if (a.dtype == STTM_F32) {
-            if (a.vec == 8) STTM_LAUNCH_GM2(float, 8); else if (a.vec == 4) STTM_LAUNCH_GM2(float, 4); else if (a.vec == 2) STTM_LAUNCH_GM2(float, 2); else STTM_LAUNCH_GM2(float, 1);
-        } else if (a.dtype == STTM_BF16) {
-            if (a.vec == 8) STTM_LAUNCH_GM2(bf16_t, 8); else if (a.vec == 4) STTM_LAUNCH_GM2(bf16_t, 4); else STTM_LAUNCH_GM2(bf16_t, 2);
-        } else {
-            if (a.vec == 8) STTM_LAUNCH_GM2(f16_t, 8); else if (a.vec == 4) STTM_LAUNCH_GM2(f16_t, 4); else STTM_LAUNCH_GM2(f16_t, 2);
-        }
-#undef STTM_LAUNCH_GM2
-        return hipGetLastError();
-    }
-#define STTM_LAUNCH_GM(TT, VV) hipLaunchKernelGGL((k_group_mean<TT, VV>), dim3(grid, n_videos), dim3(256), 0, stream, a, bp)
+#define STTM_LAUNCH_GM(TT, VV) hipLaunchKernelGGL((k_group_mean<TT, VV, 6>), dim3(grid, n_videos), dim3(256), 0, stream, a, bp)
     if (a.dtype == STTM_F32) {
         if (a.vec == 8) STTM_LAUNCH_GM(float, 8); else if (a.vec == 4) STTM_LAUNCH_GM(float, 4); else if (a.vec == 2) STTM_LAUNCH_GM(float, 2); else STTM_LAUNCH_GM(float, 1);
     } else if (a.dtype == STTM_BF16) {

@@ -208,7 +208,7 @@ LABEL_PATHS = [
     dict(fold_labels=1),                             # label stage folded into the pair kernel (runs of frame pairs, last arriver)
     dict(fold_labels=1, fold_kb=8),                  # ... with a tiny LDS budget: busy columns overflow to global scratch in-kernel
     dict(pairs_seg=4), dict(pairs_seg=16, pairs_nt=256),   # runs of frame pairs per pair workgroup
-    dict(pairs_var=9), dict(gm_var=9),               # the general pair kernel / the first form of the group-mean kernel
+    dict(pairs_var=9),                               # the general pair kernel instead of the lean 256-thread form
     dict(no_dense=1),                                # column label stage with compact ids even where the slots fit LDS uncompacted
 ]
 
@@ -220,7 +220,7 @@ def test_label_stage_paths_give_identical_results(opts):
     from oracle import sttm_oracle as O
     from sttm_amd import _lib, get_quadtree_features
     from sttm_amd.synth import synth_video
-    defaults = dict(fold_labels=0, no_fuse=0, force_gmem_labels=0, fold_kb=64, pairs_seg=0, pairs_nt=0, pairs_var=0, gm_var=0, no_dense=0)
+    defaults = dict(fold_labels=0, no_fuse=0, force_gmem_labels=0, fold_kb=64, pairs_seg=0, pairs_nt=0, pairs_var=0, no_dense=0)
     try:
         _lib.configure(**opts)
         for path in case_paths(["st_"]):

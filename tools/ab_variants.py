@@ -1,6 +1,6 @@
 """A/B of library switches on one GPU: for every `key=value[,key=value]` argument, (1) outputs bit-identical to the default
 configuration on a few videos, (2) per-kernel HIP-event times and wall time per video (drop-in API, pool of device-resident
-videos).   usage: python tools/ab_variants.py [--shape headline|prod|both] default pairs_var=2 pairs_var=3,gm_var=1 ..."""
+videos).   usage: python tools/ab_variants.py [--shape headline|prod|both] default pairs_var=9 no_dense=1,gm_split=16 ..."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
