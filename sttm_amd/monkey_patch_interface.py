@@ -1,10 +1,11 @@
 """L2 installer with the reference's names and keyword arguments (token_merging_utils/monkey_patch_interface.py:17-38).
 
 `replace_qwen2_by_sparse_attn(pattern_name, **kwargs)` dispatches on the same pattern names.  "quadtree" and "tome" --
-the two patterns on the hot path -- are implemented: like the reference they store their configuration as CLASS
-attributes on the decoder model class and overwrite its `.forward` (quadtree_attn_monkey_patch.py:177-187,
-tome_attn_monkey_patch.py:163-171).  The other names are the reference's ablations / other papers' baselines and
-raise NotImplementedError with a message that says so.
+the two patterns on the hot path -- and the baselines that share their hook ("quadtree-abl-pos", "pyrd", "dycoke-stage1",
+"octree") are implemented: like the reference they store their configuration as CLASS attributes on the decoder model
+class and overwrite its `.forward` (quadtree_attn_monkey_patch.py:177-187, tome_attn_monkey_patch.py:163-171).  Only full
+DyCoke (decode-time KV pruning), the FrameFusion baselines and the plotting variants raise NotImplementedError, with a message
+that says so.
 
 The reference pins transformers==4.45.2 and patches a verbatim copy of that version's Qwen2Model.forward.  This
 build targets the transformers that is installed (5.x decoder-layer API): the patched forward below is the

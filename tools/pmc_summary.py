@@ -12,7 +12,7 @@ import re
 import sqlite3
 import sys
 
-NAMES = {"k_spatial": "quadtree_spatial", "k_pairs": "temporal_pairs_labels", "k_col_labels": "labels_standalone",
+NAMES = {"k_spatial": "quadtree_spatial", "k_pairs": "temporal_pairs_labels", "k_pairs256": "temporal_pairs_labels", "k_col_labels": "labels_standalone",
          "k_group_mean": "group_mean", "k_slow_filter": "temporal_pairs_labels"}
 
 
