@@ -664,8 +664,8 @@ int sttm_wait_counts_early(const int32_t* counts_host, const uint64_t* early_hos
         if ((spins & 255u) == 255u) {
             clock_gettime(CLOCK_MONOTONIC, &t1);
             const long long us = (t1.tv_sec - t0.tv_sec) * 1000000ll + (t1.tv_nsec - t0.tv_nsec) / 1000;
-            if (us > timeout_us) return fail(STTM_ERR_LAUNCH, "timed out waiting for the token counts");
-            if (us > 200) sched_yield();
+            if (us > timeout_us) return STTM_ERR_TIMEOUT;
+            if (us > 300) sched_yield();
         }
     }
 }

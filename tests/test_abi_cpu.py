@@ -183,3 +183,41 @@ def test_build_tag_depends_on_the_compile_flags():
     from sttm_amd import build
     assert build.source_tag() == build.source_tag(())
     assert build.source_tag(("-DSTTM_DEV",)) != build.source_tag()
+
+
+def test_argument_block_matches_the_header_and_rejects_null():
+    """ABI v5: the ctypes mirror of sttm_merge_args has the header's fields in the header's order, the packed entry point and
+    the early wait validate their arguments without a GPU, and the early wait adds up column words the way the kernels write them."""
+    import ctypes
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "sttm_hip.h")).read()
+    body = re.search(r"typedef struct sttm_merge_args \{(.*?)\} sttm_merge_args;", hdr, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        for part in decl.split(","):
+            names.append(re.findall(r"([A-Za-z_][A-Za-z_0-9]*)\s*$", part.strip())[0])
+    assert names == [f[0] for f in _lib.MergeArgs._fields_]
+    assert re.search(r"#define\s+STTM_EARLY_SLOTS\s+64\b", hdr) and _lib.EARLY_SLOTS == 64
+    lib = _lib.load()
+    assert lib.sttm_quadtree_merge_packed(None) == _lib.ERR_ARG
+    out = (ctypes.c_int32 * 2)()
+    host = (ctypes.c_int32 * 8)()
+    early = (ctypes.c_uint64 * 64)()
+    assert lib.sttm_wait_counts_early(None, None, 0, 1, 1000, out) == _lib.ERR_ARG
+    assert lib.sttm_wait_counts_early(host, early, 65, 1, 1000, out) == _lib.ERR_ARG
+    # three columns report for seq 7: survivors 10 + 20 + 5, the last one with the list-overflow flag
+    seq = 7
+    early[0] = (seq << 32) | 10
+    early[1] = (seq << 32) | 20
+    early[2] = (seq << 32) | 0x40000000 | 5
+    assert lib.sttm_wait_counts_early(host, early, 3, seq, 1000, out) == 0 and (out[0], out[1]) == (35, 1)
+    early[2] = (seq << 32) | 0x80000000 | 5                       # the fused label stage's barrier timed out in that column
+    assert lib.sttm_wait_counts_early(host, early, 3, seq, 1000, out) == 0 and out[1] == _lib.OVF_BARRIER_TIMEOUT
+    early[1] = ((seq - 1) << 32) | 20                             # a stale word: falls back to the classic counts when they arrive
+    host[_lib.CNT_OUT], host[_lib.CNT_OVERFLOW], host[_lib.CNT_SLOTS - 1] = 77, 0, seq
+    assert lib.sttm_wait_counts_early(host, early, 3, seq, 1000, out) == 0 and (out[0], out[1]) == (77, 0)
+    host[_lib.CNT_SLOTS - 1] = seq - 1
+    assert lib.sttm_wait_counts_early(host, early, 3, seq, 2000, out) == _lib.ERR_TIMEOUT

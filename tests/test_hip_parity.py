@@ -789,3 +789,48 @@ def test_c_abi_demo_runs_without_python_or_torch():
     r = subprocess.run([exe, "32", "256"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "sum of num_patches" in r.stdout
+
+
+def test_early_column_words_agree_with_the_published_counts():
+    """ABI v5: the per-column words the label stage stores into pinned memory add up to the N' the group-mean kernel publishes,
+    for the fused, the two-launch and the global-scratch label paths and for a spatial-only call."""
+    import ctypes
+    from sttm_amd import _lib
+    from sttm_amd.synth import synth_video
+    lib = _lib.load()
+    dev = _dev()
+    x = synth_video(24, 128, 14, 14, seed=77).to(dev)
+    T, C, H, W = x.shape
+    N = T * H * W
+    nbytes = lib.sttm_quadtree_workspace_bytes(T, H, W, C, 0, 1)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    feat = torch.empty((N, C), device=dev); npatch = torch.empty(N, dtype=torch.int32, device=dev)
+    tlbr = torch.empty((N, 5), dtype=torch.int32, device=dev); counts = torch.zeros(8, dtype=torch.int32, device=dev)
+    pinned = torch.zeros(4 + 64, dtype=torch.int64).pin_memory()
+    a = _lib.MergeArgs()
+    a.x, a.stride_t, a.stride_c, a.stride_h, a.stride_w = x.data_ptr(), x.stride(0), x.stride(1), x.stride(2), x.stride(3)
+    a.T, a.C, a.H, a.W, a.dtype = T, C, H, W, 0
+    a.threshold, a.root_level = 0.85, 1
+    a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+    a.feat_out, a.npatch_out, a.tlbr_out, a.counts = feat.data_ptr(), npatch.data_ptr(), tlbr.data_ptr(), counts.data_ptr()
+    a.counts_host, a.early_host = pinned.data_ptr(), pinned.data_ptr() + 32
+    a.stream = torch.cuda.current_stream(dev).cuda_stream
+    out = (ctypes.c_int32 * 2)()
+    seq = 1000
+    try:
+        for opts in (dict(), dict(no_fuse=1), dict(force_gmem_labels=1)):
+            _lib.configure(no_fuse=0, force_gmem_labels=0)
+            _lib.configure(**opts)
+            for tthr in (0.55, -1.0):
+                seq += 1
+                a.temporal_thresh, a.seq = tthr, seq
+                assert lib.sttm_quadtree_merge_packed(ctypes.addressof(a)) == 0, _lib.last_error()
+                assert a.n_early == 16                                        # 14 x 14 at root_level 1: 4 x 4 root cells
+                assert lib.sttm_wait_counts_early(a.counts_host, a.early_host, a.n_early, seq, 2_000_000, out) == 0
+                torch.cuda.synchronize()
+                host = pinned[:4].view(torch.int32).tolist()
+                assert host[_lib.CNT_SLOTS - 1] == seq and host[_lib.CNT_OUT] == out[0] == int(counts[_lib.CNT_OUT]) and out[1] == 0
+                words = pinned[4:4 + 16].tolist()
+                assert all((w >> 32) == seq for w in words) and sum(w & 0x0fffffff for w in words) == out[0]
+    finally:
+        _lib.configure(no_fuse=0, force_gmem_labels=0)
