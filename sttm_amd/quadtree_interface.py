@@ -170,6 +170,11 @@ def _state_for(dev, idx, handle):
         with _seq_lock:
             st = _states.get(key)
             if st is None:
+                if len(_states) >= _states.limit:
+                    # the oldest state is about to be dropped: its pinned landing pad may still be written by a group-mean kernel
+                    # that is queued or running (the classic counts follow the early words) -- drain the device first (rare path:
+                    # only a caller that keeps creating streams gets here)
+                    torch.cuda.synchronize(dev)
                 st = _StreamState(dev)
                 _states[key] = st
     return st
