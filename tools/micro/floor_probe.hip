@@ -135,6 +135,48 @@ __global__ void __launch_bounds__(256) k_pairread(const f4* __restrict__ x, cons
     for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
     if (lane == 0) out[blockIdx.x * 4 + wave] = acc;
 }
+
+// the group-mean kernel's singleton path, minimal: workgroup (t, s) of 4 waves, every wave reads the frame's metadata (NMETA arrays x
+// 4 chunks of 64 slots), ranks the survivors with ballots, takes the rank congruent to its id, copies that row.  S workgroups per frame.
+template <int NMETA, bool TLBR>
+__global__ void __launch_bounds__(256) k_gm_like(const f4* __restrict__ x, const int* __restrict__ gcnt, const int* __restrict__ meta,
+                                                 const int* __restrict__ geo, const int* __restrict__ frame_cnt, int S, int HW,
+                                                 f4* __restrict__ y, int* __restrict__ tlbr) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int t = blockIdx.x / S, s = blockIdx.x - t * S;
+    const int stride = S * 4, me = s * 4 + wave;
+    int row0 = 0;
+    for (int f = lane; f < t; f += 64) row0 += frame_cnt[f];
+    int cnt[4], mt[4], gg[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int p = b * 64 + lane, pc = p < HW ? p : HW - 1;
+        cnt[b] = gcnt[t * HW + pc];
+        mt[b] = NMETA >= 2 ? meta[t * HW + pc] : 0;
+        gg[b] = NMETA >= 3 ? geo[pc] : 0;
+        if (p >= HW) cnt[b] = 0;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) row0 += __shfl_xor(row0, d, 64);
+    int j0 = 0, sel_p = -1, sel_j = 0, extra = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const unsigned long long m = __ballot(cnt[b] > 0);
+        const int j = j0 + __popcll(m & ((1ull << lane) - 1ull));
+        const unsigned long long h = __ballot(cnt[b] > 0 && (j & (stride - 1)) == me);
+        if (h) { const int l = __ffsll((long long)h) - 1; sel_p = b * 64 + l; sel_j = j0 + __popcll(m & ((1ull << l) - 1ull));
+                 extra = __builtin_amdgcn_readlane(mt[b], l) + __builtin_amdgcn_readlane(gg[b], l); }
+        j0 += __popcll(m);
+    }
+    if (sel_p < 0) return;
+    const int src = t * HW + sel_p, o = row0 + sel_j;
+    f4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = x[(size_t)src * ROW_F4 + k * 64 + lane];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) y[(size_t)o * ROW_F4 + k * 64 + lane] = v[k];
+    if (TLBR && lane == 0) { int* q = tlbr + (size_t)o * 6; q[0] = t; q[1] = sel_p; q[2] = extra; q[3] = 1; q[4] = 2; q[5] = 3; }
+}
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("ERR %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 int main() {
     const int T = 128, HW = 196, NROWS = T * HW, NOUT = 11200;
@@ -155,6 +197,17 @@ int main() {
     for (int w = 0; w < NWG; ++w) { const int t = w % 127, r = w / 127;
         for (int k = 0; k < 4 * NC; ++k) { const int p = (r * 12 + rand() % 12) % HW; pr[((size_t)w * 4 * NC + k) * 2] = t * HW + p; pr[((size_t)w * 4 * NC + k) * 2 + 1] = (t + 1) * HW + (p + rand() % 3) % HW; } }
     CK(hipMalloc(&prow, pr.size() * 4)); CK(hipMemcpy(prow, pr.data(), pr.size() * 4, hipMemcpyHostToDevice)); CK(hipMalloc(&pout, NWG * 4 * 4));
+    // metadata for k_gm_like: ~87 survivors per frame
+    std::vector<int> hg((size_t)T * HW, 0), hm((size_t)T * HW, 7), hgeo(HW, 3), hfc(T, 0);
+    for (int t = 0; t < T; ++t) { std::vector<int> sl(HW); for (int i = 0; i < HW; ++i) sl[i] = i;
+        const int ns = 87 + (t & 1);
+        for (int i = 0; i < ns; ++i) { const int j = i + rand() % (HW - i); std::swap(sl[i], sl[j]); hg[(size_t)t * HW + sl[i]] = 1; }
+        hfc[t] = ns; }
+    int *dgc, *dmt, *dgeo, *dfc, *dtl;
+    CK(hipMalloc(&dgc, hg.size() * 4)); CK(hipMalloc(&dmt, hm.size() * 4)); CK(hipMalloc(&dgeo, HW * 4)); CK(hipMalloc(&dfc, T * 4));
+    CK(hipMalloc(&dtl, (size_t)NROWS * 6 * 4));
+    CK(hipMemcpy(dgc, hg.data(), hg.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dmt, hm.data(), hm.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dgeo, hgeo.data(), HW * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dfc, hfc.data(), T * 4, hipMemcpyHostToDevice));
     const size_t nsrc4 = src_bytes / 16;
     for (int rep = 0; rep < 20; ++rep) {
 #define WARM() hipLaunchKernelGGL(k_warm, dim3((unsigned)((nsrc4 / 4 + 255) / 256)), dim3(256), 0, 0, src, nsrc4, sink)
@@ -167,6 +220,10 @@ int main() {
         WARM(); hipLaunchKernelGGL(k_gather_persist, dim3(1024), dim3(256), 0, 0, src, idx, NOUT, dst);
         WARM(); hipLaunchKernelGGL((k_gather_2stage<1>), dim3((NOUT + 3) / 4), dim3(256), 0, 0, src, idx, meta, NOUT, dst);
         WARM(); hipLaunchKernelGGL((k_gather_2stage<2>), dim3((NOUT + 7) / 8), dim3(256), 0, 0, src, idx, meta, NOUT, dst);
+        WARM(); hipLaunchKernelGGL((k_gm_like<1, false>), dim3(T * 32), dim3(256), 0, 0, src, dgc, dmt, dgeo, dfc, 32, HW, dst, dtl);
+        WARM(); hipLaunchKernelGGL((k_gm_like<3, false>), dim3(T * 32), dim3(256), 0, 0, src, dgc, dmt, dgeo, dfc, 32, HW, dst, dtl);
+        WARM(); hipLaunchKernelGGL((k_gm_like<3, true>), dim3(T * 32), dim3(256), 0, 0, src, dgc, dmt, dgeo, dfc, 32, HW, dst, dtl);
+        WARM(); hipLaunchKernelGGL((k_gm_like<3, true>), dim3(T * 16), dim3(256), 0, 0, src, dgc, dmt, dgeo, dfc, 16, HW, dst, dtl);
         WARM(); hipLaunchKernelGGL((k_pairread<2, 2>), dim3(NWG), dim3(256), 0, 0, src, prow, NWG, pout);
         WARM(); hipLaunchKernelGGL((k_pairread<2, 4>), dim3(NWG), dim3(256), 0, 0, src, prow, NWG, pout);
         WARM(); hipLaunchKernelGGL((k_pairread<2, 1>), dim3(NWG), dim3(256), 0, 0, src, prow, NWG, pout);
