@@ -67,5 +67,29 @@ int main(int argc, char** argv) {
            N, n_out, 100.0 * n_out / N, h_counts[STTM_CNT_NODES], h_counts[STTM_CNT_CANDIDATES], h_counts[STTM_CNT_EDGES],
            h_counts[STTM_CNT_ITERS], h_counts[STTM_CNT_OVERFLOW]);
     printf("sum of num_patches = %ld (must be %d)\n", patches, N);
-    return (patches == N && h_counts[STTM_CNT_OVERFLOW] == 0 && n_out > 0 && n_out < N) ? 0 : 4;
+    if (!(patches == N && h_counts[STTM_CNT_OVERFLOW] == 0 && n_out > 0 && n_out < N)) return 4;
+
+    // The same merge through the argument block (ABI v5) with N' read from pinned host memory while the feature kernel may still
+    // be running: no stream synchronisation between the call and the moment the caller knows how many rows it got.
+    int32_t* counts_host = nullptr;
+    uint64_t* early_host = nullptr;
+    HIP_OK(hipHostMalloc((void**)&counts_host, STTM_CNT_SLOTS * sizeof(int32_t), hipHostMallocDefault));
+    HIP_OK(hipHostMalloc((void**)&early_host, STTM_EARLY_SLOTS * sizeof(uint64_t), hipHostMallocDefault));
+    for (int i = 0; i < STTM_CNT_SLOTS; ++i) counts_host[i] = 0;
+    for (int i = 0; i < STTM_EARLY_SLOTS; ++i) early_host[i] = 0;
+    sttm_merge_args g = {};
+    g.x = dx; g.stride_t = (int64_t)H * W * C; g.stride_c = 1; g.stride_h = (int64_t)W * C; g.stride_w = C;
+    g.T = T; g.C = C; g.H = H; g.W = W; g.dtype = STTM_F32;
+    g.threshold = 0.85f; g.temporal_thresh = 0.55f; g.root_level = 1;
+    g.workspace = ws; g.workspace_bytes = ws_bytes;
+    g.feat_out = feat; g.npatch_out = (int32_t*)npatch; g.tlbr_out = (int32_t*)tlbr; g.counts = (int32_t*)counts;
+    g.counts_host = counts_host; g.early_host = early_host; g.seq = 1; g.stream = stream;
+    const int rc2 = sttm_quadtree_merge_packed(&g);
+    if (rc2 != STTM_OK) { fprintf(stderr, "sttm_quadtree_merge_packed: %d %s\n", rc2, sttm_last_error()); return 5; }
+    int32_t early[2] = {0, 0};
+    const int rc3 = sttm_wait_counts_early(counts_host, early_host, g.n_early, g.seq, 2000000, early);
+    if (rc3 != STTM_OK) { fprintf(stderr, "sttm_wait_counts_early: %d\n", rc3); return 5; }
+    printf("argument-block call: N' = %d from %d column words before any stream synchronisation (first call: %d)\n", early[0], g.n_early, n_out);
+    HIP_OK(hipStreamSynchronize(stream));
+    return (early[0] == n_out && early[1] == 0) ? 0 : 6;
 }
