@@ -64,6 +64,46 @@ __device__ __forceinline__ unsigned long long pack_score(float v, int j) {
     return ((unsigned long long)u << 32) | (unsigned long long)(0xffffffffu - (unsigned)j);
 }
 
+// Running max / argmax of one lane's scores of a 64 (j) x 32*QI (i) wave tile: acc[p][q][e] is the score of a-row q against
+// candidate  jlane + p*32 + (e&3) + 8*(e>>2)  (jlane = tile origin + wave's j offset + 4 * lane half).  A lane meets its candidates in
+// ascending j -- inside a tile and from tile to tile -- so the first maximum (torch.max; tome_token_merger.py:36) is the first score
+// STRICTLY above the running one: for tiles that lie inside [0, nb) that is a compare and two selects per score, no branch.
+// Only the last, partial tile takes the general form (round 2's, which cost ~30 instructions and an exec-mask branch per score).
+typedef float tome_f32x16 __attribute__((ext_vector_type(16)));
+template <int QI, typename RoundFn>
+__device__ __forceinline__ void tome_running_max(const tome_f32x16 (&acc)[2][QI], float (&bestv)[QI], int (&bestj)[QI], int jlane, int nb,
+                                                 bool inside, RoundFn rnd) {
+    if (inside) {
+#pragma unroll
+        for (int q = 0; q < QI; ++q) {
+            float bv = bestv[q];
+            int bc = -1;
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float v = rnd(acc[p][q][e]);
+                    const bool gt = v > bv;
+                    bc = gt ? p * 32 + (e & 3) + 8 * (e >> 2) : bc;
+                    bv = gt ? v : bv;
+                }
+            bestj[q] = bc >= 0 ? jlane + bc : bestj[q];
+            bestv[q] = bv;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < QI; ++q)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int j = jlane + p * 32 + (e & 3) + 8 * (e >> 2);
+                    const float v = rnd(acc[p][q][e]);
+                    if (j < nb && (v > bestv[q] || (v == bestv[q] && j < bestj[q]))) { bestv[q] = v; bestj[q] = j; }
+                }
+    }
+}
+
 // Workgroups are dispatched round-robin over the 8 XCDs (blockIdx % 8), each with its own L2.  Logical ids are handed out so
 // that one XCD gets a CONTIGUOUS range: the workgroups of one a-tile (its jsplit j-parts, which re-read the same a rows) and of
 // neighbouring a-tiles (which stream the same b rows at the same time) then share an L2 instead of each pulling its operands
@@ -156,16 +196,7 @@ __global__ void __launch_bounds__(256, 2) k_tome_match(const float* __restrict__
             }
         }
         // running max over this tile: lane owns column i = wi*64 + q*32 + lcol; rows j = (e&3) + 8*(e>>2) + 4*lhalf
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int p = 0; p < 2; ++p)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int j = j0 + wj * 64 + p * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
-                    const float v = acc[p][q][e];
-                    if (j < nb && (v > bestv[q] || (v == bestv[q] && j < bestj[q]))) { bestv[q] = v; bestj[q] = j; }
-                }
+        tome_running_max<2>(acc, bestv, bestj, j0 + wj * 64 + 4 * lhalf, nb, j0 + TM_J <= nb, [](float v) { return v; });
     }
     // publish: packed 64-bit max per a-row (combines the two lane halves, the two j-waves and the j-splits)
 #pragma unroll
@@ -333,16 +364,7 @@ __global__ void __launch_bounds__(256, 2) k_tome_match16(const uint16_t* __restr
             }
         }
         // the score tensor of the reference has the input dtype: round before comparing (ties -> smaller j)
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int p = 0; p < 2; ++p)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int j = j0 + wj * 64 + p * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
-                    const float v = tome_round<T>(acc[p][q][e]);
-                    if (j < nb && (v > bestv[q] || (v == bestv[q] && j < bestj[q]))) { bestv[q] = v; bestj[q] = j; }
-                }
+        tome_running_max<2>(acc, bestv, bestj, j0 + wj * 64 + 4 * lhalf, nb, j0 + TM_J <= nb, [](float v) { return tome_round<T>(v); });
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -511,16 +533,7 @@ __global__ void __launch_bounds__(128 * WJ, 2) k_tome_match_split(const uint16_t
             }
         }
         // running max over this tile (on the scaled scores: the factor 2^-24 is applied once, at the end)
-#pragma unroll
-        for (int q = 0; q < QI; ++q)
-#pragma unroll
-            for (int p = 0; p < 2; ++p)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int j = j0 + wj * 64 + p * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
-                    const float v = acc[p][q][e];
-                    if (j < nb && (v > bestv[q] || (v == bestv[q] && j < bestj[q]))) { bestv[q] = v; bestj[q] = j; }
-                }
+        tome_running_max<QI>(acc, bestv, bestj, j0 + wj * 64 + 4 * lhalf, nb, j0 + TJ <= nb, [](float v) { return v; });
     }
 #pragma unroll
     for (int q = 0; q < QI; ++q) {
@@ -548,7 +561,17 @@ typedef __attribute__((address_space(3))) void* tome_lptr;
 constexpr int TG_T = 256;                       // tile side
 constexpr int TG_BUF = 65536;                   // bytes of one stage: [matrix A, B][plane][256 rows][KS * 2 bytes]
 
-template <int NP, int TERMS, typename T>
+// Round 3: (a) the running max of a tile product that lies inside [0, nb) is branch-free -- a lane meets its candidates in
+// ascending j (p, then e), so "first maximum" is a strict `>` and costs a compare and two selects per score; written as
+// `if (j < nb && (v > best || (v == best && j < bestj)))` the compiler produced ~30 instructions and an exec-mask branch per score,
+// 3 800 instructions per wave and tile product (23 % of a four-term product's MFMA time, about as long as a one-term product's);
+// (b) one-plane kernels request step n+1's fragments after the first four MFMAs of step n: the compiler waits with lgkmcnt(0) in
+// front of a step's first MFMA, so reads issued before it were waited for at once (8 MFMAs per step cannot hide that; the 32 of the
+// two-plane kernels can: no difference there).  Results are bit-identical.
+// ABL (dev builds, STTM_TOME_ABL): 1 = no DMA after the prologue (MFMA side alone), 2 = no MFMAs (DMA + barriers + fragment reads alone),
+// 5 = MFMAs alone (no fragment reads, barriers or DMA in the loop), 6 = MFMAs + fragment reads (no barriers, no DMA): outputs invalid
+// in all four; 3 = the round-2 form (general running max everywhere, reads in front), 4 = reads after the FIRST MFMA.
+template <int NP, int TERMS, typename T, int ABL = 0>
 __global__ void __launch_bounds__(512, 2) k_tome_match_glds(const uint16_t* __restrict__ ap, const uint16_t* __restrict__ bp,
                                                              int na, int nb, int D, int jsplit,
                                                              unsigned long long* __restrict__ best /*[na]*/) {
@@ -588,6 +611,7 @@ __global__ void __launch_bounds__(512, 2) k_tome_match_glds(const uint16_t* __re
     }
     // piece c of stage st (tile jt_lo + st / NK, k0 = (st % NK) * KS) into buffer st & 1
     auto issue_piece = [&](int c, int st) {
+        if ((ABL == 1 || ABL == 5 || ABL == 6) && st > 1) return;
         const int g = wave + 8 * c, buf = st & 1;
         const int j0 = (jt_lo + st / NK) * TG_T, k0 = (st % NK) * KS;
         if (c < 4) {
@@ -602,6 +626,7 @@ __global__ void __launch_bounds__(512, 2) k_tome_match_glds(const uint16_t* __re
     const int a_off = (wi * 128 + lcol) * RB, b_off = NP * PLANE + (wj * 64 + lcol) * RB;
     struct Frag { vec b[2][NP], a[QI][NP]; };
     auto read_frag = [&](Frag& f, int st, int step) {
+        if (ABL == 5 && st + step > 0) return;                 // MFMAs alone: the first fragments for ever
         const char* base = tg_smem + (st & 1) * TG_BUF;
         const int coff = ((step * 2 + lhalf) ^ sw) * 16;
 #pragma unroll
@@ -637,6 +662,7 @@ __global__ void __launch_bounds__(512, 2) k_tome_match_glds(const uint16_t* __re
     __syncthreads();
     Frag fr[2];
     read_frag(fr[0], 0, 0);
+    if (ABL == 5) fr[1] = fr[0];
 
     for (int st = 0; st < S; ++st) {
 #pragma unroll
@@ -645,13 +671,17 @@ __global__ void __launch_bounds__(512, 2) k_tome_match_glds(const uint16_t* __re
             Frag& nxt = fr[(step + 1) & 1];
             const bool last = step == NSTEP - 1;
             __builtin_amdgcn_sched_barrier(0);      // the MFMAs of the step before stay in front of this step's barrier / reads
+            constexpr int late_n = (NP == 1 && ABL != 3) ? (ABL == 4 ? 1 : QI) : 0;   // MFMAs in front of the next step's fragment reads
+            constexpr bool late = late_n > 0;
             if (!last) {
-                read_frag(nxt, st, step + 1);
+                if (!late) read_frag(nxt, st, step + 1);
             } else {
                 // every wave has read all of stage st (the reads of this step were issued a step ago; __syncthreads waits for
                 // them); stage st+1 has landed once every wave's own pieces have
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
+                if (ABL != 5 && ABL != 6) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                }
                 if (st + 1 < S) read_frag(nxt, st + 1, 0);
             }
             __builtin_amdgcn_sched_barrier(0);      // the reads stay in front of the MFMAs they overlap with
@@ -661,10 +691,23 @@ __global__ void __launch_bounds__(512, 2) k_tome_match_glds(const uint16_t* __re
                 // l.l, l.h, h.l, h.h (small terms first); one plane: the only term is h.h
                 const int pb = NP == 2 && (term == 0 || term == 1), pa = NP == 2 && (term == 0 || term == 2);
 #pragma unroll
-                for (int p = 0; p < 2; ++p)
+                for (int p = 0; p < 2; ++p) {
 #pragma unroll
-                    for (int q = 0; q < QI; ++q)
-                        acc[p][q] = TomeMfma<T>::run(cur.b[p][pb], cur.a[q][pa], acc[p][q]);
+                    for (int q = 0; q < QI; ++q) {
+                        if (ABL != 2) acc[p][q] = TomeMfma<T>::run(cur.b[p][pb], cur.a[q][pa], acc[p][q]);
+                        else asm volatile("" :: "v"(cur.b[p][pb]), "v"(cur.a[q][pa]));      // the fragment reads stay
+                        if (late_n == 1 && !last && term == 4 - TERMS && p == 0 && q == 0) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            read_frag(nxt, st, step + 1);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    if (late_n == QI && !last && term == 4 - TERMS && p == 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        read_frag(nxt, st, step + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
                 if (last) {
                     const int gi = term - (4 - TERMS);
                     if (feed) {
@@ -678,17 +721,14 @@ __global__ void __launch_bounds__(512, 2) k_tome_match_glds(const uint16_t* __re
         if ((st + 1) % NK == 0) {
             // end of a tile product: running max (split: on the scaled scores, the factor 2^-24 is applied once at the end)
             const int j0 = (jt_lo + st / NK) * TG_T;
+            tome_running_max<QI>(acc, bestv, bestj, j0 + wj * 64 + 4 * lhalf, nb, ABL != 3 && j0 + TG_T <= nb,
+                                 [](float v) { return NP == 1 ? tome_round<T>(v) : v; });
 #pragma unroll
-            for (int q = 0; q < QI; ++q)
+            for (int p = 0; p < 2; ++p)
 #pragma unroll
-                for (int p = 0; p < 2; ++p)
+                for (int q = 0; q < QI; ++q)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int j = j0 + wj * 64 + p * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
-                        const float v = NP == 1 ? tome_round<T>(acc[p][q][e]) : acc[p][q][e];
-                        if (j < nb && (v > bestv[q] || (v == bestv[q] && j < bestj[q]))) { bestv[q] = v; bestj[q] = j; }
-                        acc[p][q][e] = 0.f;
-                    }
+                    for (int e = 0; e < 16; ++e) acc[p][q][e] = 0.f;
         }
     }
 #pragma unroll
@@ -977,6 +1017,16 @@ int sttm_tome_step(const void* x_, const float* size, const int64_t* idx, int n,
         if (big) {
             const int it = (p.na + TG_T - 1) / TG_T;
             const int js = pick_jsplit(it, TG_T, 1);
+#ifdef STTM_DEV
+            const int abl = getenv("STTM_TOME_ABL") ? atoi(getenv("STTM_TOME_ABL")) : 0;
+            if (abl == 1) hipLaunchKernelGGL((k_tome_match_glds<2, 4, f16_t, 1>), dim3(it * js), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
+            else if (abl == 2) hipLaunchKernelGGL((k_tome_match_glds<2, 4, f16_t, 2>), dim3(it * js), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
+            else if (abl == 3) hipLaunchKernelGGL((k_tome_match_glds<2, 4, f16_t, 3>), dim3(it * js), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
+            else if (abl == 4) hipLaunchKernelGGL((k_tome_match_glds<2, 4, f16_t, 4>), dim3(it * js), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
+            else if (abl == 5) hipLaunchKernelGGL((k_tome_match_glds<2, 4, f16_t, 5>), dim3(it * js), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
+            else if (abl == 6) hipLaunchKernelGGL((k_tome_match_glds<2, 4, f16_t, 6>), dim3(it * js), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
+            else
+#endif
             if (terms == 4) hipLaunchKernelGGL((k_tome_match_glds<2, 4, f16_t>), dim3(it * js), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
             else hipLaunchKernelGGL((k_tome_match_glds<2, 3, f16_t>), dim3(it * js), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
         } else {
@@ -995,13 +1045,21 @@ int sttm_tome_step(const void* x_, const float* size, const int64_t* idx, int n,
         const bool big = split == 4 || split == 6 || (split != 3 && split != 5 && p.na >= 3072);
         const int it = (p.na + TG_T - 1) / TG_T;
         const int js = pick_jsplit(it, TG_T, 1);
+#ifdef STTM_DEV
+        const int abl16 = getenv("STTM_TOME_ABL") ? atoi(getenv("STTM_TOME_ABL")) : 0;
+        constexpr int ABL16A = 3, ABL16B = 4;
+#else
+        constexpr int abl16 = 0, ABL16A = 0, ABL16B = 0;
+#endif
 #define STTM_TOME_16(TT)                                                                                                            \
         do {                                                                                                                        \
             if (n_head == 1 && C % 8 == 0 && C <= 4096 && reinterpret_cast<uintptr_t>(x_) % 16 == 0)                              \
                 hipLaunchKernelGGL((k_tome_normalize16<TT, 8>), dim3(ngrid), dim3(256), 0, stream, x_, n, C, n_head, p.D, p.Dp, ap, bp); \
             else                                                                                                                    \
                 hipLaunchKernelGGL((k_tome_normalize16<TT, 1>), dim3(ngrid), dim3(256), 0, stream, x_, n, C, n_head, p.D, p.Dp, ap, bp); \
-            if (big) hipLaunchKernelGGL((k_tome_match_glds<1, 1, TT>), dim3(it * js), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best); \
+            if (big && abl16 == 3) hipLaunchKernelGGL((k_tome_match_glds<1, 1, TT, ABL16A>), dim3(it * js), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best); \
+            else if (big && abl16 == 4) hipLaunchKernelGGL((k_tome_match_glds<1, 1, TT, ABL16B>), dim3(it * js), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best); \
+            else if (big) hipLaunchKernelGGL((k_tome_match_glds<1, 1, TT>), dim3(it * js), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best); \
             else hipLaunchKernelGGL(k_tome_match16<TT>, dim3(itiles * jsplit), dim3(256), 0, stream, ap, bp, p.na, p.nb, p.Dp, jsplit, best); \
         } while (0)
         if (dtype == STTM_BF16) STTM_TOME_16(bf16_t); else STTM_TOME_16(f16_t);

@@ -680,6 +680,60 @@ def test_tome_match_kernel_variants(mode):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
+def test_tome_first_maximum_on_exact_ties(dtype):
+    """torch.max returns the FIRST maximum (tome_token_merger.py:36).  The match kernels keep a running maximum per lane with a
+    strict `>` on tiles that lie inside [0, nb) and the general form on the last, partial tile: rows of b that are exact copies of one
+    another -- inside a 32-row sub-tile, across the wave tiles of a workgroup, across tiles, across the j-parts of different
+    workgroups and inside the partial tile -- must all resolve to the smallest j, in every kernel variant."""
+    from sttm_amd import _lib
+    lib = _lib.load()
+    dev = _dev()
+    code = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[dtype]
+    g = torch.Generator().manual_seed(77)
+    C = 256
+    try:
+        for na in (100, 700, 3400):                                     # below one tile / ragged 128-tiles / the 256-tile kernel's range
+            n = 2 * na
+            base = torch.randn(8, C, generator=g)
+            x = torch.randn(n, C, generator=g) * 0.05
+            which = torch.randint(0, 8, (na,), generator=g)
+            x[0::2] += base[which]                                      # a rows lean towards one of 8 directions
+            perm, m = torch.randperm(na, generator=g), max(6, na // 12)
+            copies = {k: perm[k * m:(k + 1) * m].sort().values for k in range(8)}       # disjoint sets of b rows
+            for k, js in copies.items():
+                x[1::2][js] = base[k] * 3.0                             # (writes through: x[1::2] is a view) b rows js are identical
+            x = x.to(dtype).to(dev)
+            u = x.double()
+            u = u / u.norm(dim=-1, keepdim=True)
+            first = torch.full((8,), na, dtype=torch.long)
+            for k, js in copies.items():
+                first[k] = int(js[0])
+            for mode in ((0, 3, 4, 5, 6) if dtype == torch.float32 else (3, 4)):
+                _lib.configure(tome_split=mode)
+                r = n // 2
+                nbytes = lib.sttm_tome_workspace_bytes(n, C, 1)
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                xo = torch.empty((n - r, C), dtype=dtype, device=dev); so = torch.empty(n - r, device=dev)
+                io = torch.empty(n - r, dtype=torch.int64, device=dev)
+                nmax = torch.empty(na, device=dev); nidx = torch.empty(na, dtype=torch.int32, device=dev)
+                idx = torch.arange(n, device=dev)
+                rc = lib.sttm_tome_step(x.data_ptr(), None, idx.data_ptr(), n, C, 1, r, code, ws.data_ptr(), nbytes, xo.data_ptr(),
+                                        so.data_ptr(), io.data_ptr(), nmax.data_ptr(), nidx.data_ptr(),
+                                        torch.cuda.current_stream().cuda_stream)
+                _lib.raise_for(rc)
+                torch.cuda.synchronize()
+                got = nidx.long().cpu()
+                # every a row's best candidates are the copies of its own direction (cos ~ 1 against <= 0.3 for anything else):
+                # the winner must be the FIRST copy
+                want = first[which]
+                bad = (got != want).nonzero().flatten()
+                assert bad.numel() == 0, (f"{dtype} na={na} tome_split={mode}: {bad.numel()} rows did not take the first of their tied "
+                                          f"candidates, e.g. row {int(bad[0])}: got {int(got[bad[0]])}, first copy {int(want[bad[0]])}")
+    finally:
+        _lib.configure(tome_split=1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_tome_tile128_and_tile256_kernels_are_bit_identical(dtype):
     """The 128-tile and the 256-tile LDS-DMA match kernels add the same products in the same order into one fp32 accumulator:
     forcing either must give the same bits (features, ids, best scores) -- on a clip smaller than a tile, a ragged one and one
