@@ -193,6 +193,9 @@ int sttm_quadtree_merge_batch(int n_videos, const void* const* x, int64_t stride
  *                 the fp32-input MFMA kernel measures 1.4e-6), kernel picked by size; 2: the same without l.l (bound 4.8e-7);
  *                 0: fp32-input MFMA (v_mfma_f32_32x32x2_f32), 2.9x slower; 3 / 4: force the 128-tile / 256-tile kernel, 5 / 6
  *                 the same with three terms (tests)
+ *   "tome_flat"   256-tile ToMe match kernels: 1 (default) spread all tile products evenly over one workgroup per CU when that
+ *                 shortens the per-CU critical path against the best per-a-tile split (69 x 69 tiles at T = 180: 19 instead of 23
+ *                 products per workgroup), 0 never, 2 always.  Same scores, same first-maximum argmax.
  */
 int sttm_configure(const char* key, int value);
 

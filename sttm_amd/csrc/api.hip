@@ -24,7 +24,7 @@ int fail(int code, const char* fmt, ...) {
 // Tuning / test switches: defaults from STTM_<KEY> environment variables, read ONCE; sttm_configure overrides them.
 // None of them changes results.
 struct Config {
-    int pairs_seg, pairs_nt, pairs_var, no_dense, gm_split, label_nt, vec16, vec32, fold_kb, fold_labels, no_fuse, force_gmem_labels, tome_split;
+    int pairs_seg, pairs_nt, pairs_var, no_dense, gm_split, label_nt, vec16, vec32, fold_kb, fold_labels, no_fuse, force_gmem_labels, tome_split, tome_flat;
 };
 int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
@@ -46,6 +46,7 @@ Config& config() {
         d.no_fuse = env_int("STTM_NO_FUSE", env_int("STTM_NO_FUSE_LABELS", 0));
         d.force_gmem_labels = env_int("STTM_FORCE_GMEM_LABELS", 0);
         d.tome_split = env_int("STTM_TOME_SPLIT", 1);
+        d.tome_flat = env_int("STTM_TOME_FLAT", 1);
         return d;
     }();
     return c;
@@ -472,6 +473,7 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
 
 namespace sttm {
 int tome_split_mode() { return config().tome_split; }
+int tome_flat_mode() { return config().tome_flat; }
 }  // namespace sttm
 
 extern "C" {
@@ -488,7 +490,7 @@ int sttm_configure(const char* key, int value) {
     Config& c = config();
     struct { const char* name; int* slot; } keys[] = {
         {"pairs_seg", &c.pairs_seg}, {"pairs_nt", &c.pairs_nt}, {"pairs_var", &c.pairs_var}, {"no_dense", &c.no_dense}, {"gm_split", &c.gm_split}, {"label_nt", &c.label_nt},
-        {"vec16", &c.vec16}, {"vec32", &c.vec32}, {"fold_kb", &c.fold_kb}, {"fold_labels", &c.fold_labels}, {"no_fuse", &c.no_fuse}, {"tome_split", &c.tome_split},
+        {"vec16", &c.vec16}, {"vec32", &c.vec32}, {"fold_kb", &c.fold_kb}, {"fold_labels", &c.fold_labels}, {"no_fuse", &c.no_fuse}, {"tome_split", &c.tome_split}, {"tome_flat", &c.tome_flat},
         {"force_gmem_labels", &c.force_gmem_labels},
     };
     for (auto& k : keys)

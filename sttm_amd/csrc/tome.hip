@@ -591,31 +591,41 @@ __global__ void __launch_bounds__(512, 2) k_tome_match_glds(const uint16_t* __re
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wave & 1, wj = wave >> 1;
     const int lid = tome_xcd_logical_id();
-    const int itile = lid / jsplit, jpart = lid % jsplit;
-    const int i0 = itile * TG_T;
+    // A workgroup owns a contiguous range [p_lo, p_hi) of tile products in row-major order (p = itile * jtiles + jtile).
+    // jsplit > 0: the j tiles of ONE a-tile in jsplit parts (grid = itiles * jsplit).  jsplit == 0: all products spread evenly over
+    // the grid (one workgroup per CU), a range may cross into the next a-tile(s) -- 69 x 69 tiles (T = 180) on 256 CUs are 23 products
+    // per workgroup on 207 workgroups the first way and 18 or 19 on 256 the second.  Either way a lane meets the candidates of an
+    // a-row in ascending j; rows are published (packed atomicMax) and the running max reset whenever the a-tile changes.
     const int jtiles = (nb + TG_T - 1) / TG_T;
-    const int jt_lo = (int)((long long)jtiles * jpart / jsplit), jt_hi = (int)((long long)jtiles * (jpart + 1) / jsplit);
+    int p_lo, p_hi;
+    if (jsplit > 0) {
+        const int itile = lid / jsplit, jpart = lid % jsplit;
+        p_lo = itile * jtiles + (int)((long long)jtiles * jpart / jsplit);
+        p_hi = itile * jtiles + (int)((long long)jtiles * (jpart + 1) / jsplit);
+    } else {
+        const long long total = (long long)((na + TG_T - 1) / TG_T) * jtiles;
+        p_lo = (int)(total * lid / gridDim.x);
+        p_hi = (int)(total * (lid + 1) / gridDim.x);
+    }
     const int lcol = lane & 31, lhalf = lane >> 5;
     const int NK = D / KS;                        // stages per tile product
-    const int S = (jt_hi - jt_lo) * NK;           // stages of this workgroup
+    const int S = (p_hi - p_lo) * NK;             // stages of this workgroup
     if (S <= 0) return;
 
     const int prow = lane / CPR;
     auto piece_row = [&](int g) { return (g % PPM) * RPP + prow; };
     auto src_chunk = [&](int g) { return (lane % CPR) ^ ((piece_row(g) / R256) & (CPR - 1)); };
-    const char* asrc[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int g = wave + 8 * c, plane = (g / PPM) % NP;
-        asrc[c] = reinterpret_cast<const char*>(ap + ((int64_t)plane * na + min(i0 + piece_row(g), na - 1)) * D + src_chunk(g) * 8);
-    }
-    // piece c of stage st (tile jt_lo + st / NK, k0 = (st % NK) * KS) into buffer st & 1
+    // piece c of stage st (product p_lo + st / NK, k0 = (st % NK) * KS) into buffer st & 1
     auto issue_piece = [&](int c, int st) {
         if ((ABL == 1 || ABL == 5 || ABL == 6) && st > 1) return;
         const int g = wave + 8 * c, buf = st & 1;
-        const int j0 = (jt_lo + st / NK) * TG_T, k0 = (st % NK) * KS;
+        const int prod = p_lo + st / NK, it = prod / jtiles;
+        const int j0 = (prod - it * jtiles) * TG_T, k0 = (st % NK) * KS;
         if (c < 4) {
-            __builtin_amdgcn_global_load_lds((tome_gptr)(asrc[c] + (int64_t)k0 * 2), (tome_lptr)(tg_smem + buf * TG_BUF + g * 1024), 16, 0, 0);
+            // (the address is rebuilt per piece, like b's: four pointers kept per lane cost the two-plane kernel its last registers)
+            const int plane = (g / PPM) % NP;
+            const char* src = reinterpret_cast<const char*>(ap + ((int64_t)plane * na + min(it * TG_T + piece_row(g), na - 1)) * D + k0 + src_chunk(g) * 8);
+            __builtin_amdgcn_global_load_lds((tome_gptr)src, (tome_lptr)(tg_smem + buf * TG_BUF + g * 1024), 16, 0, 0);
         } else {
             const int plane = (g / PPM) % NP;
             const char* src = reinterpret_cast<const char*>(bp + ((int64_t)plane * nb + min(j0 + piece_row(g), nb - 1)) * D + k0 + src_chunk(g) * 8);
@@ -720,7 +730,8 @@ __global__ void __launch_bounds__(512, 2) k_tome_match_glds(const uint16_t* __re
         }
         if ((st + 1) % NK == 0) {
             // end of a tile product: running max (split: on the scaled scores, the factor 2^-24 is applied once at the end)
-            const int j0 = (jt_lo + st / NK) * TG_T;
+            const int prod = p_lo + st / NK, it = prod / jtiles, jt = prod - it * jtiles;
+            const int j0 = jt * TG_T;
             tome_running_max<QI>(acc, bestv, bestj, j0 + wj * 64 + 4 * lhalf, nb, ABL != 3 && j0 + TG_T <= nb,
                                  [](float v) { return NP == 1 ? tome_round<T>(v) : v; });
 #pragma unroll
@@ -729,12 +740,17 @@ __global__ void __launch_bounds__(512, 2) k_tome_match_glds(const uint16_t* __re
                 for (int q = 0; q < QI; ++q)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[p][q][e] = 0.f;
-        }
-    }
+            if (st + 1 == S || jt + 1 == jtiles) {
+                // last product of this a-tile in the range: publish its rows, start over for the next a-tile
 #pragma unroll
-    for (int q = 0; q < QI; ++q) {
-        const int i = i0 + wi * 128 + q * 32 + lcol;
-        if (i < na && bestj[q] != 0x7fffffff) atomicMax(best + i, pack_score(NP == 2 ? bestv[q] * kSplitUnscale : bestv[q], bestj[q]));
+                for (int q = 0; q < QI; ++q) {
+                    const int i = it * TG_T + wi * 128 + q * 32 + lcol;
+                    if (i < na && bestj[q] != 0x7fffffff)
+                        atomicMax(best + i, pack_score(NP == 2 ? bestv[q] * kSplitUnscale : bestv[q], bestj[q]));
+                    bestv[q] = -INFINITY; bestj[q] = 0x7fffffff;
+                }
+            }
+        }
     }
 }
 
@@ -998,6 +1014,21 @@ int sttm_tome_step(const void* x_, const float* size, const int64_t* idx, int n,
         }
         return jsplit;
     };
+    // 256-tile kernels: all tile products spread evenly over one workgroup per CU (jsplit = 0, grid = it * js with js = 1 below)
+    // when that shortens the per-CU critical path against the best per-a-tile split; "tome_flat" 0 = never, 2 = always (tests)
+    auto pick_flat = [&](int& it, int& js) {
+        const int mode = tome_flat_mode();
+        const int jtiles = (p.nb + TG_T - 1) / TG_T;
+        const long total = (long)it * jtiles;
+        const long wgs = (long)it * js;
+        const long split_cost = ((wgs + n_cu - 1) / n_cu) * ((jtiles + js - 1) / js);
+        const long flat_wgs = total < n_cu ? total : n_cu;
+        const long flat_cost = (total + flat_wgs - 1) / flat_wgs;
+        // measured (tools/tome_ab_flat_prof.py): 69 x 69 tiles (T = 180) -- the best per-a-tile split is 4 761 one-product workgroups
+        // in 19 rounds: bf16 686 -> 561 us, fp32 2 372 -> 2 277 us with 256 workgroups of 18 / 19 products; 49 x 49 (T = 128), where
+        // the split fits one round (245 workgroups of 9 / 10): bf16 279 against 291 us flat -- so flat only replaces multi-round grids
+        if (mode == 2 || (mode == 1 && (flat_cost < split_cost || (wgs > n_cu && flat_cost <= split_cost)))) { it = (int)flat_wgs; js = 0; }
+    };
     const int itiles = (p.na + TM_I - 1) / TM_I;
     const int jsplit = pick_jsplit(itiles, TM_J, 2);
     const int split = tome_split_mode();
@@ -1015,20 +1046,21 @@ int sttm_tome_step(const void* x_, const float* size, const int64_t* idx, int n,
         const int terms = (split == 2 || split == 5 || split == 6) ? 3 : 4;
         const bool big = split == 4 || split == 6 || ((split == 1 || split == 2) && p.na >= 3072);
         if (big) {
-            const int it = (p.na + TG_T - 1) / TG_T;
-            const int js = pick_jsplit(it, TG_T, 1);
+            int it = (p.na + TG_T - 1) / TG_T;
+            int js = pick_jsplit(it, TG_T, 1);
+            pick_flat(it, js);
 #ifdef STTM_DEV
             const int abl = getenv("STTM_TOME_ABL") ? atoi(getenv("STTM_TOME_ABL")) : 0;
-            if (abl == 1) hipLaunchKernelGGL((k_tome_match_glds<2, 4, f16_t, 1>), dim3(it * js), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
-            else if (abl == 2) hipLaunchKernelGGL((k_tome_match_glds<2, 4, f16_t, 2>), dim3(it * js), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
-            else if (abl == 3) hipLaunchKernelGGL((k_tome_match_glds<2, 4, f16_t, 3>), dim3(it * js), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
-            else if (abl == 4) hipLaunchKernelGGL((k_tome_match_glds<2, 4, f16_t, 4>), dim3(it * js), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
-            else if (abl == 5) hipLaunchKernelGGL((k_tome_match_glds<2, 4, f16_t, 5>), dim3(it * js), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
-            else if (abl == 6) hipLaunchKernelGGL((k_tome_match_glds<2, 4, f16_t, 6>), dim3(it * js), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
+            if (abl == 1) hipLaunchKernelGGL((k_tome_match_glds<2, 4, f16_t, 1>), dim3(js ? it * js : it), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
+            else if (abl == 2) hipLaunchKernelGGL((k_tome_match_glds<2, 4, f16_t, 2>), dim3(js ? it * js : it), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
+            else if (abl == 3) hipLaunchKernelGGL((k_tome_match_glds<2, 4, f16_t, 3>), dim3(js ? it * js : it), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
+            else if (abl == 4) hipLaunchKernelGGL((k_tome_match_glds<2, 4, f16_t, 4>), dim3(js ? it * js : it), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
+            else if (abl == 5) hipLaunchKernelGGL((k_tome_match_glds<2, 4, f16_t, 5>), dim3(js ? it * js : it), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
+            else if (abl == 6) hipLaunchKernelGGL((k_tome_match_glds<2, 4, f16_t, 6>), dim3(js ? it * js : it), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
             else
 #endif
-            if (terms == 4) hipLaunchKernelGGL((k_tome_match_glds<2, 4, f16_t>), dim3(it * js), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
-            else hipLaunchKernelGGL((k_tome_match_glds<2, 3, f16_t>), dim3(it * js), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
+            if (terms == 4) hipLaunchKernelGGL((k_tome_match_glds<2, 4, f16_t>), dim3(js ? it * js : it), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
+            else hipLaunchKernelGGL((k_tome_match_glds<2, 3, f16_t>), dim3(js ? it * js : it), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
         } else {
             const size_t lds = (size_t)(2 * TM_I + 2 * TM_J) * (TM_K + 8) * 2;
             if (terms == 4) hipLaunchKernelGGL((k_tome_match_split<TM_K, 2, 2, 4>), dim3(itiles * jsplit), dim3(256), lds, stream, ap, bp, p.na, p.nb, p.Dp, jsplit, best);
@@ -1043,8 +1075,9 @@ int sttm_tome_step(const void* x_, const float* size, const int64_t* idx, int n,
         uint16_t* ap = reinterpret_cast<uint16_t*>(ahat);
         uint16_t* bp = reinterpret_cast<uint16_t*>(bhat);
         const bool big = split == 4 || split == 6 || (split != 3 && split != 5 && p.na >= 3072);
-        const int it = (p.na + TG_T - 1) / TG_T;
-        const int js = pick_jsplit(it, TG_T, 1);
+        int it = (p.na + TG_T - 1) / TG_T;
+        int js = pick_jsplit(it, TG_T, 1);
+        pick_flat(it, js);
 #ifdef STTM_DEV
         const int abl16 = getenv("STTM_TOME_ABL") ? atoi(getenv("STTM_TOME_ABL")) : 0;
         constexpr int ABL16A = 3, ABL16B = 4;
@@ -1057,9 +1090,9 @@ int sttm_tome_step(const void* x_, const float* size, const int64_t* idx, int n,
                 hipLaunchKernelGGL((k_tome_normalize16<TT, 8>), dim3(ngrid), dim3(256), 0, stream, x_, n, C, n_head, p.D, p.Dp, ap, bp); \
             else                                                                                                                    \
                 hipLaunchKernelGGL((k_tome_normalize16<TT, 1>), dim3(ngrid), dim3(256), 0, stream, x_, n, C, n_head, p.D, p.Dp, ap, bp); \
-            if (big && abl16 == 3) hipLaunchKernelGGL((k_tome_match_glds<1, 1, TT, ABL16A>), dim3(it * js), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best); \
-            else if (big && abl16 == 4) hipLaunchKernelGGL((k_tome_match_glds<1, 1, TT, ABL16B>), dim3(it * js), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best); \
-            else if (big) hipLaunchKernelGGL((k_tome_match_glds<1, 1, TT>), dim3(it * js), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best); \
+            if (big && abl16 == 3) hipLaunchKernelGGL((k_tome_match_glds<1, 1, TT, ABL16A>), dim3(js ? it * js : it), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best); \
+            else if (big && abl16 == 4) hipLaunchKernelGGL((k_tome_match_glds<1, 1, TT, ABL16B>), dim3(js ? it * js : it), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best); \
+            else if (big) hipLaunchKernelGGL((k_tome_match_glds<1, 1, TT>), dim3(js ? it * js : it), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best); \
             else hipLaunchKernelGGL(k_tome_match16<TT>, dim3(itiles * jsplit), dim3(256), 0, stream, ap, bp, p.na, p.nb, p.Dp, jsplit, best); \
         } while (0)
         if (dtype == STTM_BF16) STTM_TOME_16(bf16_t); else STTM_TOME_16(f16_t);

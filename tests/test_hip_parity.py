@@ -692,7 +692,8 @@ def test_tome_first_maximum_on_exact_ties(dtype):
     g = torch.Generator().manual_seed(77)
     C = 256
     try:
-        for na in (100, 700, 3400):                                     # below one tile / ragged 128-tiles / the 256-tile kernel's range
+        for na in (100, 700, 3400, 4500):                               # below one tile / ragged 128-tiles / the 256-tile kernel's range /
+                                                                        # more 256-tile products than CUs (flat ranges cross a-tiles)
             n = 2 * na
             base = torch.randn(8, C, generator=g)
             x = torch.randn(n, C, generator=g) * 0.05
@@ -708,8 +709,8 @@ def test_tome_first_maximum_on_exact_ties(dtype):
             first = torch.full((8,), na, dtype=torch.long)
             for k, js in copies.items():
                 first[k] = int(js[0])
-            for mode in ((0, 3, 4, 5, 6) if dtype == torch.float32 else (3, 4)):
-                _lib.configure(tome_split=mode)
+            for mode, flat in [(m, 1) for m in ((0, 3, 4, 5, 6) if dtype == torch.float32 else (3, 4))] + [(4, 2), (4, 0)]:
+                _lib.configure(tome_split=mode, tome_flat=flat)
                 r = n // 2
                 nbytes = lib.sttm_tome_workspace_bytes(n, C, 1)
                 ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -727,10 +728,35 @@ def test_tome_first_maximum_on_exact_ties(dtype):
                 # the winner must be the FIRST copy
                 want = first[which]
                 bad = (got != want).nonzero().flatten()
-                assert bad.numel() == 0, (f"{dtype} na={na} tome_split={mode}: {bad.numel()} rows did not take the first of their tied "
+                assert bad.numel() == 0, (f"{dtype} na={na} tome_split={mode} tome_flat={flat}: {bad.numel()} rows did not take the first of their tied "
                                           f"candidates, e.g. row {int(bad[0])}: got {int(got[bad[0]])}, first copy {int(want[bad[0]])}")
     finally:
-        _lib.configure(tome_split=1)
+        _lib.configure(tome_split=1, tome_flat=1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
+def test_tome_flat_and_per_tile_work_splits_are_bit_identical(dtype):
+    """The 256-tile match kernels either give a workgroup the j tiles of ONE a-tile (tome_flat 0) or a contiguous range of all tile
+    products, which may cross a-tiles (tome_flat 2: rows published and the running max reset at every a-tile change): same scores,
+    same first-maximum argmax, hence the same bits -- on a clip below one tile (one product), ragged ones (partial last a- and
+    b-tiles, ranges that cross several a-tiles) and the T = 180 shape of BASELINE config 5 where the flat split is the default."""
+    from sttm_amd import _lib, get_tome_features
+    from sttm_amd.synth import synth_video
+    dev = _dev()
+    try:
+        for T, C, ratio in [(1, 1024, 0.5), (9, 1000, 0.7), (45, 256, 0.85), (100, 128, 0.6), (180, 128, 0.5)]:
+            if dtype != torch.float32 and C % 2:
+                continue
+            x = synth_video(T, C, 14, 14, seed=500 + T, dtype=dtype).to(dev)
+            _lib.configure(tome_split=4 if dtype == torch.float32 else 4)        # the 256-tile kernel at every size
+            outs = []
+            for flat in (0, 2, 1):
+                _lib.configure(tome_flat=flat)
+                outs.append(get_tome_features(x, ratio, "video"))
+            for flat, (f, i) in zip((2, 1), outs[1:]):
+                assert torch.equal(i, outs[0][1]) and torch.equal(f, outs[0][0]), f"{dtype} T={T} C={C} r={ratio}: tome_flat {flat} differs from 0"
+    finally:
+        _lib.configure(tome_split=1, tome_flat=1)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
