@@ -8,6 +8,8 @@ from sttm_amd.synth import synth_video
 dev = torch.device("cuda:0")
 T, C = int(os.environ.get("T", "128")), 1024
 x = synth_video(T, C, 14, 14, seed=3, device=dev, gen_device=dev)
+if os.environ.get("DTYPE"):                      # DTYPE=bfloat16 / float16: the one-plane match kernels
+    x = x.to(getattr(torch, os.environ["DTYPE"]))
 for ratio in (0.5, 0.7, 0.85):
     get_tome_features(x, ratio, "video")
     torch.cuda.synchronize()
