@@ -296,6 +296,10 @@ def main():
         n_val = 4 * world
         ids_v = shard_videos(n_val, world, rank)
         loc = []
+        # the CPU generator's many tiny ops crawl with one thread per core of a 128-core NUMA node (10 s per 16-frame clip,
+        # 14 CPU-minutes for this leg): a handful of threads draws the same tensors in well under a second
+        cpu_threads = torch.get_num_threads()
+        torch.set_num_threads(min(cpu_threads, 8))
         for vid in ids_v:
             x = synth_video(T, C, H, W, seed=900000 + vid, device=dev)             # CPU generator: the same tensor on every rank
             _, _, tl = get_quadtree_features(x, thr, tthr, root)
@@ -311,6 +315,7 @@ def main():
         okt = torch.tensor([1 if ok else 0], device=dev)
         if dist is not None:
             dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        torch.set_num_threads(cpu_threads)
         validate = {"videos": n_val, "index_rows_gathered": int((full[:, 0] >= 0).sum()), "cross_rank_index_match": bool(okt.item())}
         log(f"validate: {validate}")
 
