@@ -29,6 +29,8 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+HBM_COPY_GBS = 6300.0        # MI355X_MICROARCH.md: what a plain device copy achieves on this part (~6.3 TB/s)
+L3_BYTES = 256e6             # Infinity Cache: pools of the timed legs are sized past it
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA = the fp32 vector rate
 MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/FP16 MFMA, dense (32x32x16)
 KERNELS = ["quadtree_spatial", "temporal_pairs_labels", "labels_standalone", "group_mean"]
@@ -144,28 +146,33 @@ CONFIGS = [
 
 def run_configs(dev, rank, world, timed, log):
     """videos/s, algorithmic bytes B (read every token once, write every merged token once + 24 B of metadata) and
-    B / time / 8 TB/s for every secondary configuration, through the drop-in API with device-resident inputs (pool of 3 distinct
-    videos per shape).  The ToMe half of config 5 (T=180, r=0.5) rides along with its flop roofline."""
+    B / time / 8 TB/s for every secondary configuration, through the drop-in API with device-resident inputs.  The pool of every
+    shape holds >= 300 MB of distinct videos (> the 256 MB Infinity Cache: a video is not cache-resident from its previous use;
+    round 3 used 3 videos per shape, which left C1 and C2 inside the cache).  The ToMe half of config 5 (T=180, r=0.5) rides along
+    with its flop roofline."""
     from sttm_amd.quadtree_interface import get_quadtree_features
     from sttm_amd.synth import synth_video
     from sttm_amd.tome_interface import get_tome_features
     out = []
     for name, T, C, H, W, dtn, thr, tthr in CONFIGS:
         dt = getattr(torch, dtn)
-        pool = [synth_video(T, C, H, W, seed=7000 + 10 * rank + i, dtype=dt, device=dev, gen_device=dev) for i in range(3)]
-        kept = [get_quadtree_features(x, thr, tthr, 1)[0].shape[0] for x in pool]          # warm-up + N' of each
-        reps = max(24, min(300, int(0.25 / (5e-8 * T * H * W * C / 1024 + 2e-5))))
-
-        def run(pool=pool, reps=reps, thr=thr, tthr=tthr):
-            for i in range(reps):
-                get_quadtree_features(pool[i % 3], thr, tthr, 1)
-        vps = timed(run, reps) / world                                                      # per GPU
         eb = 4 if dt == torch.float32 else 2
+        npool = max(3, int(-(-300e6 // (eb * C * T * H * W))))
+        pool = [synth_video(T, C, H, W, seed=7000 + 100 * rank + i, dtype=dt, device=dev, gen_device=dev) for i in range(npool)]
+        kept = [get_quadtree_features(x, thr, tthr, 1)[0].shape[0] for x in pool]          # warm-up + N' of each
+        reps = max(24, 2 * npool, min(300, int(0.25 / (5e-8 * T * H * W * C / 1024 + 2e-5))))
+
+        def run(pool=pool, reps=reps, thr=thr, tthr=tthr, npool=npool):
+            for i in range(reps):
+                get_quadtree_features(pool[i % npool], thr, tthr, 1)
+        vps = timed(run, reps) / world                                                      # per GPU
         n_out = sum(kept) / len(kept)
         B = eb * C * T * H * W + eb * C * n_out + 24 * n_out
         out.append({"config": name, "videos_per_s_per_gpu": round(vps, 1), "us_per_video": round(1e6 / vps, 1),
-                    "keep_ratio": round(n_out / (T * H * W), 4), "algorithmic_MB": round(B / 1e6, 2),
-                    "achieved_GBs": round(B * vps / 1e9, 1), "frac": round(B * vps / 1e9 / HBM_PEAK_GBS, 4)})
+                    "keep_ratio": round(n_out / (T * H * W), 4), "algorithmic_MB": round(B / 1e6, 2), "pool_videos": npool,
+                    "pool_MB": round(npool * eb * C * T * H * W / 1e6, 1),
+                    "achieved_GBs": round(B * vps / 1e9, 1), "frac": round(B * vps / 1e9 / HBM_PEAK_GBS, 4),
+                    "frac_of_copy_rate": round(B * vps / 1e9 / HBM_COPY_GBS, 4)})
         log(f"config {name}: {vps:.1f} videos/s, frac {out[-1]['frac']}")
         del pool
     # config 5's ToMe half: T = 180, ratio 0.5 (run_vidqa.sh:44), fp32 and the bf16 hidden states of production
@@ -395,6 +402,36 @@ def main():
         del xb
         log(f"tome extension: {tome_vps:.1f} videos/s = {ext['tome_extension']['roofline']['achieved']} TFLOP/s")
 
+    # ---- hook leg: what the patched decoder forward does around the merge (quadtree_attn_monkey_patch.py:88-117) at the production
+    #      shape: bf16 hidden states [1, 20 system + T*196 visual + 60 instruction tokens, 3584]; slice -> merge -> concat as the
+    #      reference writes it (merge + torch.cat) against the fused form (the kernels write into the new hidden-state buffer) ----
+    if not args.no_extensions:
+        from sttm_amd import get_quadtree_features_into, patch_hooks
+        Ch, n_sys, n_inst = 3584, 20, 60
+        hs_pool = []
+        for sidx in range(3):                              # 3 x 180 MB of hidden states: past the Infinity Cache
+            vid = synth_video(T, Ch, H, W, seed=8000 + 10 * rank + sidx, dtype=torch.bfloat16, device=dev, gen_device=dev)
+            vis = vid.permute(0, 2, 3, 1).reshape(1, T * H * W, Ch)
+            hs_pool.append(torch.cat([torch.randn(1, n_sys, Ch, device=dev, dtype=torch.bfloat16), vis,
+                                      torch.randn(1, n_inst, Ch, device=dev, dtype=torch.bfloat16)], 1).contiguous())
+            del vid, vis
+        pos = torch.arange(hs_pool[0].shape[1], device=dev).unsqueeze(0)
+        hook = {}
+        for label, into in (("merge_then_cat", None), ("fused_into_new_buffer", get_quadtree_features_into)):
+            def run_hook(into=into, n=48):
+                for it in range(n):
+                    patch_hooks.quadtree_merge_llava(hs_pool[it % 3], pos, n_sys, T * H * W, T, get_quadtree_features, thr, tthr, root,
+                                                     False, merge_into_fn=into)
+            run_hook(n=6)
+            hook[label + "_us_per_call"] = round(1e6 / (timed(run_hook, 48) / world), 1)
+        hook["shape"] = f"hidden_states [1, {n_sys} + {T}*{H * W} + {n_inst}, {Ch}] bf16, STTM(0.85, 0.55, root 1)"
+        hook["what"] = ("patch_hooks.quadtree_merge_llava = the reference hook's slice -> get_quadtree_features -> torch.cat -> index "
+                        "arithmetic -> position-id truncation; fused = get_quadtree_features_into writes the merged rows straight into the "
+                        "new hidden-state buffer (one copy of the system / instruction rows, none of the merged rows)")
+        ext["hook_extension"] = hook
+        log(f"hook extension: {hook['merge_then_cat_us_per_call']} us three-step, {hook['fused_into_new_buffer_us_per_call']} us fused")
+        del hs_pool
+
     # ---- configs leg: every BASELINE.json configuration + the production shapes, drop-in API, a few hundred ms each --------
     configs = None
     if not args.no_configs:
@@ -440,7 +477,7 @@ def main():
     dom_gbs = kernel_bytes[dom] / (avg_ms[dom] * 1e-3) / 1e9
     pipe_gbs = pipeline_bytes / (wall_ms * 1e-3) / 1e9    # B over the time ONE video takes in the timed region
     # HBM traffic from the PMC counters: only if the committed passes were taken on THIS build of the library
-    traffic = traffic_tag = None
+    traffic = traffic_tag = traffic_where = None
     pmc_path = os.path.join(REPO, "profiles", "pmc_traffic.json")
     build_tag = _lib.build_tag()
     if os.path.exists(pmc_path):
@@ -449,16 +486,20 @@ def main():
             if rec.get("workload") == f"T{T}_14x14x1024_f32_sttm_0.85_0.55" and rec.get("build_tag") == build_tag:
                 traffic = rec.get("hbm_bytes_per_video")
                 traffic_tag = rec.get("tag")
+                traffic_where = (f"builder's MI355X box (gpurun), profiles/{rec.get('tag')}_pmc_traffic.md, library build tag {rec.get('build_tag')} "
+                                 "== the tag of the library loaded now; NOT re-measured during this run (PMC passes need rocprofv3)")
         except Exception:  # noqa: BLE001
             traffic = None
     roofline = {
         "bound": "hbm", "scope": "pipeline: one get_quadtree_features call (SURVEY 8d: B / wall time per video of the timed region); "
                                  "the dominant kernel's own figure is under dominant_kernel",
         "achieved": round(pipe_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(pipe_gbs / HBM_PEAK_GBS, 4),
-        "traffic": traffic, "traffic_profile": traffic_tag, "build_tag": build_tag,
+        "frac_of_copy_rate": round(pipe_gbs / HBM_COPY_GBS, 4), "copy_rate_GBs": HBM_COPY_GBS,
+        "traffic": traffic, "traffic_profile": traffic_tag, "traffic_measured_on": traffic_where, "build_tag": build_tag,
         "algorithmic_MB_per_video": round(pipeline_bytes / 1e6, 2), "wall_ms_per_video": round(wall_ms, 4),
         "event_span_ms_per_video": round(event_span_ms, 4),
         "dominant_kernel": {"kernel": KERNELS[dom], "achieved": round(dom_gbs, 1), "frac": round(dom_gbs / HBM_PEAK_GBS, 4),
+                            "frac_of_copy_rate": round(dom_gbs / HBM_COPY_GBS, 4),
                             "algorithmic_MB": round(kernel_bytes[dom] / 1e6, 2), "ms": round(avg_ms[dom], 4)},
         "kernel_ms": {k: round(v, 4) for k, v in zip(KERNELS, avg_ms)},
         "kernel_ms_note": "HIP-event intervals recorded by the library on the launch stream during a separate leg; the event "
@@ -502,6 +543,8 @@ def main():
         log(f"cpu baseline: {done} videos in {spent:.2f} s with {best_thr} threads; {match}/{checked} index-exact")
         host = host_cpu_facts()
         cpu = {"value": round(done / spent, 3), "unit": "videos/s", "cores": best_thr, "threads": best_thr,
+               "cores_meaning": "torch intra-op threads the oracle ran on (the bench contract's `cores` = threads actually used); the host's "
+                                "physical core count is host_physical_cores",
                "host_logical_cpus": host["logical_cpus"], "host_physical_cores": host["physical_cores"], "host_cpu": host["model"],
                "kind": "port",
                "sample": f"{done} runs over {len(sample)} distinct synth-v1 videos (the GPU pool), T={T} 14x14x1024 fp32, "

@@ -77,7 +77,7 @@ int main(int argc, char** argv) {
     HIP_OK(hipHostMalloc((void**)&early_host, STTM_EARLY_SLOTS * sizeof(uint64_t), hipHostMallocDefault));
     for (int i = 0; i < STTM_CNT_SLOTS; ++i) counts_host[i] = 0;
     for (int i = 0; i < STTM_EARLY_SLOTS; ++i) early_host[i] = 0;
-    sttm_merge_args g = {};
+    sttm_merge_args g = {};          // (flags = 0: defaults)
     g.x = dx; g.stride_t = (int64_t)H * W * C; g.stride_c = 1; g.stride_h = (int64_t)W * C; g.stride_w = C;
     g.T = T; g.C = C; g.H = H; g.W = W; g.dtype = STTM_F32;
     g.threshold = 0.85f; g.temporal_thresh = 0.55f; g.root_level = 1;

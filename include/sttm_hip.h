@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STTM_ABI_VERSION 5
+#define STTM_ABI_VERSION 6
 
 #define STTM_F32 0
 #define STTM_BF16 1
@@ -53,7 +53,7 @@ extern "C" {
 #define STTM_CNT_OUT 3        /* N' : merged tokens written to the outputs                           */
 #define STTM_CNT_ITERS 4      /* label-propagation iterations                                        */
 #define STTM_CNT_OVERFLOW 5   /* != 0 : outputs invalid.  Bit 6 (STTM_OVF_BARRIER_TIMEOUT): the in-kernel grid barrier of the fused
-                                 label stage timed out (other streams held the CUs) -- repeat the call with sttm_configure("no_fuse", 1);
+                                 label stage timed out (other streams held the CUs) -- repeat the call with STTM_FLAG_NO_FUSE;
                                  lower bits: an internal list overflowed (never expected) */
 #define STTM_OVF_BARRIER_TIMEOUT 64
 #define STTM_CNT_LEAFNODES 6  /* spatial-stage nodes that are single 1x1 tokens (their rows are never copied) */
@@ -132,6 +132,10 @@ int sttm_wait_counts(const int32_t* counts_host, int seq, int timeout_us);
  * barrier timed out (STTM_OVF_BARRIER_TIMEOUT), bit 30 = an internal list overflowed.
  */
 #define STTM_EARLY_SLOTS 64
+/* Per-call options (ABI v6).  STTM_FLAG_NO_FUSE: THIS call runs the label stage as two launches (no in-kernel grid barrier, no
+ * residency assumption) -- what a caller does after counts[STTM_CNT_OVERFLOW] reported STTM_OVF_BARRIER_TIMEOUT, without touching
+ * the process-wide "no_fuse" switch that other threads' calls read. */
+#define STTM_FLAG_NO_FUSE 1
 typedef struct sttm_merge_args {
     const void* x; int64_t stride_t, stride_c, stride_h, stride_w;
     int32_t T, C, H, W, dtype;
@@ -143,6 +147,7 @@ typedef struct sttm_merge_args {
     int32_t n_early;                 /* OUT */
     uint64_t* early_host;
     void* const* events; void* stream;
+    int32_t flags;                   /* ABI v6: per-call options, STTM_FLAG_* (0 = defaults) */
 } sttm_merge_args;
 int sttm_quadtree_merge_packed(sttm_merge_args* args);
 /* Waits until either all n_early column words carry `seq` (then out[0] = N', out[1] = overflow flags in the encoding of
@@ -167,7 +172,7 @@ int sttm_quadtree_merge_batch(int n_videos, const void* const* x, int64_t stride
                               float threshold, float temporal_thresh, int root_level, int weighted_avg, int head_dim, int slow_ver,
                               void* workspace, size_t workspace_stride,
                               void* const* feat_out, int32_t* const* npatch_out, int32_t* const* tlbr_out, int32_t* counts,
-                              int32_t* counts_host, int seq, void* const* events, void* stream);
+                              int32_t* counts_host, int seq, void* const* events, void* stream, int flags /* STTM_FLAG_* */);
 
 /*
  * Tuning and test switches (process-wide; none of them changes results, except "tome_split" within the fp32 rounding noise of
@@ -184,6 +189,7 @@ int sttm_quadtree_merge_batch(int n_videos, const void* const* x, int64_t stride
  *   "fold_labels" 1: run a column's label stage inside the pair kernel, in the column's last workgroup to finish (default 0:
  *                 stand-alone label kernel; the folded form is no faster on MI355X and is kept for experiments)
  *   "pairs_var"   9: the general pair kernel instead of the lean 256-thread form (tests / A-B)
+ *   "k1_var"      development build only (A/B): 1 = 3-level trees run the general spatial body (the one deeper trees use)
  *   "no_dense"    1: column label stage always on compact ids (default: columns of <= 4096 slots work on their slots directly)
  *   "no_fuse"     1: stand-alone label stage as two launches (no in-kernel grid barrier)
  *   "force_gmem_labels"  1: label stage on global scratch instead of LDS (the path of columns too large for LDS)

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libsttm_hip_dev.so" if os.environ.get("ST
 
 STTM_F32, STTM_BF16, STTM_F16 = 0, 1, 2
 ERR_ARG, ERR_UNSUPPORTED, ERR_LAUNCH, ERR_INDEX, ERR_PARITY, ERR_TIMEOUT = -1, -2, -3, -4, -5, -6
-ABI_VERSION = 5            # STTM_ABI_VERSION of include/sttm_hip.h this binding was written for
+ABI_VERSION = 6            # STTM_ABI_VERSION of include/sttm_hip.h this binding was written for
 CNT_NODES, CNT_CANDIDATES, CNT_EDGES, CNT_OUT, CNT_ITERS, CNT_OVERFLOW, CNT_LEAFNODES, CNT_SLOTS = 0, 1, 2, 3, 4, 5, 6, 8
 OVF_BARRIER_TIMEOUT = 64   # STTM_OVF_BARRIER_TIMEOUT
 EVENT_SLOTS = 5            # STTM_EVENT_SLOTS
@@ -32,7 +32,7 @@ SIGNATURES = {
     "sttm_quadtree_merge_async": (_i, [_vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _f, _i, _i, _i, _i,
                                        _vp, _sz, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "sttm_quadtree_merge_batch": (_i, [_i, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _f, _i, _i, _i, _i,
-                                       _vp, _sz, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+                                       _vp, _sz, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i]),
     "sttm_configure": (_i, [ctypes.c_char_p, _i]),
     "sttm_wait_counts": (_i, [_vp, _i, _i]),
     "sttm_quadtree_merge_packed": (_i, [_vp]),
@@ -54,7 +54,7 @@ SIGNATURES = {
 
 
 class MergeArgs(ctypes.Structure):
-    """sttm_merge_args of include/sttm_hip.h (ABI v5): the argument block of sttm_quadtree_merge_packed."""
+    """sttm_merge_args of include/sttm_hip.h (ABI v6): the argument block of sttm_quadtree_merge_packed."""
     _fields_ = [("x", _vp), ("stride_t", _i64), ("stride_c", _i64), ("stride_h", _i64), ("stride_w", _i64),
                 ("T", ctypes.c_int32), ("C", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("dtype", ctypes.c_int32),
                 ("threshold", _f), ("temporal_thresh", _f),
@@ -62,7 +62,7 @@ class MergeArgs(ctypes.Structure):
                 ("workspace", _vp), ("workspace_bytes", _sz),
                 ("feat_out", _vp), ("npatch_out", _vp), ("tlbr_out", _vp), ("counts", _vp),
                 ("counts_host", _vp), ("seq", ctypes.c_int32), ("n_early", ctypes.c_int32), ("early_host", _vp),
-                ("events", _vp), ("stream", _vp)]
+                ("events", _vp), ("stream", _vp), ("flags", ctypes.c_int32)]
 
 
 _lib = None

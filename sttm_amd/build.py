@@ -48,6 +48,13 @@ def source_tag(extra_flags=()):
     return h.hexdigest()[:12]
 
 
+def flags_tag(extra_flags=()):
+    """Hash of the compile flags alone: when IT changes every object is rebuilt; a changed source only rebuilds the objects that
+    are older than it (and api.o, which carries the source + flags tag)."""
+    import hashlib
+    return hashlib.sha256(("\0".join(list(FLAGS) + sorted(extra_flags))).encode()).hexdigest()[:12]
+
+
 def build(force=False, verbose=False, extra_flags=(), dev=False):
     """dev=True builds libsttm_hip_dev.so with -DSTTM_DEV (the measurement hooks of tools/*_ticks.py, tools/k1_ablate.py);
     the product library never contains them."""
@@ -60,15 +67,19 @@ def build(force=False, verbose=False, extra_flags=(), dev=False):
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     tag = source_tag(extra_flags) + ("-dev" if dev else "")
     tag_file = os.path.join(objdir, ".build_tag")
-    old_tag = open(tag_file).read().strip() if os.path.exists(tag_file) else ""
+    old = open(tag_file).read().split() if os.path.exists(tag_file) else []
+    old_tag = old[0] if old else ""
+    ftag = flags_tag(extra_flags)
+    flags_changed = len(old) < 2 or old[1] != ftag        # (a tag file of an older layout: rebuild once)
     objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
         extra = [f'-DSTTM_BUILD_TAG="{tag}"'] if src == "api.hip" else []
-        # a changed tag = changed sources OR changed flags: every object is rebuilt (the flags apply to all of them)
-        if force or _stale(o, [s] + hdrs) or old_tag != tag:
+        # changed FLAGS rebuild every object (they apply to all of them); a changed source rebuilds the objects older than it, plus
+        # api.o, which has the source + flags tag baked in (sttm_build_tag)
+        if force or flags_changed or _stale(o, [s] + hdrs) or (src == "api.hip" and old_tag != tag):
             jobs.append([_hipcc(), *FLAGS, *extra_flags, *extra, "-c", s, "-o", o])
     def run(cmd):
         if verbose:
@@ -83,7 +94,7 @@ def build(force=False, verbose=False, extra_flags=(), dev=False):
     if force or jobs or _stale(lib, objs):
         run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs])
     with open(tag_file, "w") as fh:
-        fh.write(tag + "\n")
+        fh.write(tag + "\n" + ftag + "\n")
     return lib
 
 

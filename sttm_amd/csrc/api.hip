@@ -24,7 +24,7 @@ int fail(int code, const char* fmt, ...) {
 // Tuning / test switches: defaults from STTM_<KEY> environment variables, read ONCE; sttm_configure overrides them.
 // None of them changes results.
 struct Config {
-    int pairs_seg, pairs_nt, pairs_var, no_dense, gm_split, label_nt, vec16, vec32, fold_kb, fold_labels, no_fuse, force_gmem_labels, tome_split, tome_flat;
+    int pairs_seg, pairs_nt, pairs_var, k1_var, no_dense, gm_split, label_nt, vec16, vec32, fold_kb, fold_labels, no_fuse, force_gmem_labels, tome_split, tome_flat;
 };
 int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
@@ -36,6 +36,7 @@ Config& config() {
         d.pairs_seg = env_int("STTM_PAIRS_SEG", 0);
         d.pairs_nt = env_int("STTM_PAIRS_NT", 0);
         d.pairs_var = env_int("STTM_PAIRS_VAR", 0);
+        d.k1_var = env_int("STTM_K1_VAR", 0);
         d.no_dense = env_int("STTM_NO_DENSE", 0);
         d.gm_split = env_int("STTM_GM_SPLIT", 0);
         d.label_nt = env_int("STTM_LABEL_NT", 1024);
@@ -315,7 +316,7 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
                 void* workspace, size_t workspace_stride,
                 void* const* feat_out, int32_t* const* npatch_out, int32_t* const* tlbr_out, int32_t* counts,
                 int32_t* counts_host, int seq, void* const* events, hipStream_t stream,
-                uint64_t* early_host = nullptr, int* n_early = nullptr) {
+                uint64_t* early_host = nullptr, int* n_early = nullptr, int flags = 0) {
     if (n_early) *n_early = 0;
     if (!x || !workspace || !feat_out || !npatch_out || !tlbr_out || !counts) return fail(STTM_ERR_ARG, "null pointer argument");
     if (T < 1 || C < 1) return fail(STTM_ERR_ARG, "T and C must be positive");
@@ -383,6 +384,7 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
     // dense [T*H*W, C] input: the rows of 1x1 nodes are read from x by the later kernels instead of being copied to S
     const bool dense = stride_w == C && stride_h == (int64_t)W * C && stride_t == (int64_t)H * W * C;
     sa.leaves_in_x = dense ? 1 : 0;
+    sa.k1_var = cfg.k1_var;
     sa.S = b.S; sa.meta = b.meta; sa.inrm = b.inrm; sa.rc_list = b.rc_list;
     sa.rc_stride = p.rc_stride;
     sa.lab_row = b.lab_row; sa.gcnt = b.gcnt; sa.cgeo = b.cgeo;
@@ -407,7 +409,7 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
     ta.slow_ver = slow_ver ? 1 : 0;
     ta.max_slots = p.max_slots;
     ta.force_gmem = cfg.force_gmem_labels ? 1 : 0;
-    ta.no_fuse = cfg.no_fuse ? 1 : 0;
+    ta.no_fuse = (cfg.no_fuse || (flags & STTM_FLAG_NO_FUSE)) ? 1 : 0;
     ta.no_dense = cfg.no_dense ? 1 : 0;
     ta.want_fold = cfg.fold_labels ? 1 : 0;
     ta.fold_kb = cfg.fold_kb > 0 ? cfg.fold_kb : 64;
@@ -489,7 +491,7 @@ int sttm_configure(const char* key, int value) {
     if (!key) return fail(STTM_ERR_ARG, "null key");
     Config& c = config();
     struct { const char* name; int* slot; } keys[] = {
-        {"pairs_seg", &c.pairs_seg}, {"pairs_nt", &c.pairs_nt}, {"pairs_var", &c.pairs_var}, {"no_dense", &c.no_dense}, {"gm_split", &c.gm_split}, {"label_nt", &c.label_nt},
+        {"pairs_seg", &c.pairs_seg}, {"pairs_nt", &c.pairs_nt}, {"pairs_var", &c.pairs_var}, {"k1_var", &c.k1_var}, {"no_dense", &c.no_dense}, {"gm_split", &c.gm_split}, {"label_nt", &c.label_nt},
         {"vec16", &c.vec16}, {"vec32", &c.vec32}, {"fold_kb", &c.fold_kb}, {"fold_labels", &c.fold_labels}, {"no_fuse", &c.no_fuse}, {"tome_split", &c.tome_split}, {"tome_flat", &c.tome_flat},
         {"force_gmem_labels", &c.force_gmem_labels},
     };
@@ -542,7 +544,7 @@ int sttm_quadtree_merge_packed(sttm_merge_args* g) {
     const int rc = merge_group(1, &x, g->stride_t, g->stride_c, g->stride_h, g->stride_w, g->T, g->C, g->H, g->W, g->dtype, g->threshold,
                                g->temporal_thresh, g->root_level, g->weighted_avg, g->head_dim, g->slow_ver, g->workspace, g->workspace_bytes,
                                &feat, &np, &tl, g->counts, g->counts_host, g->seq, g->events, reinterpret_cast<hipStream_t>(g->stream),
-                               g->early_host, &n_early);
+                               g->early_host, &n_early, g->flags);
     g->n_early = n_early;
     return rc;
 }
@@ -552,7 +554,7 @@ int sttm_quadtree_merge_batch(int n_videos, const void* const* x, int64_t stride
                               float threshold, float temporal_thresh, int root_level, int weighted_avg, int head_dim, int slow_ver,
                               void* workspace, size_t workspace_stride,
                               void* const* feat_out, int32_t* const* npatch_out, int32_t* const* tlbr_out, int32_t* counts,
-                              int32_t* counts_host, int seq, void* const* events, void* stream_) {
+                              int32_t* counts_host, int seq, void* const* events, void* stream_, int flags) {
     if (n_videos < 1) return fail(STTM_ERR_ARG, "n_videos must be >= 1");
     if (!x || !feat_out || !npatch_out || !tlbr_out || !counts || !workspace) return fail(STTM_ERR_ARG, "null pointer argument");
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
@@ -570,7 +572,7 @@ int sttm_quadtree_merge_batch(int n_videos, const void* const* x, int64_t stride
                                    reinterpret_cast<char*>(workspace) + (size_t)v0 * workspace_stride, workspace_stride,
                                    feat_out + v0, npatch_out + v0, tlbr_out + v0, counts + (size_t)v0 * STTM_CNT_SLOTS,
                                    counts_host ? counts_host + (size_t)v0 * STTM_CNT_SLOTS : nullptr, seq + v0,
-                                   events ? ev : nullptr, stream);
+                                   events ? ev : nullptr, stream, nullptr, nullptr, flags);
         if (rc != STTM_OK) return rc;
     }
     return STTM_OK;

@@ -49,6 +49,7 @@ struct SpatialArgs {
     int n_head;               // 0 = whole-vector cosine; > 0 = per-head cosine averaged over n_head heads
     int head_lanes;           // head_dim / vec: adjacent lanes that own one head (power of two <= 64)
     int leaves_in_x;          // x is a dense [T*H*W, C] matrix: 1x1 nodes are NOT copied to S (consumers read x)
+    int k1_var;               // option (A/B, tests): 1 = interior root cells also run the general body
     // outputs
     void* S;                  // [T*H*W, C] node features at their origin rows (input dtype)
     uint32_t* meta;           // [T*H*W] 0 = no node starts here, else (y2 << 16) | x2

@@ -38,22 +38,33 @@ def gather_indices(local_ids, local_indices, n_videos, max_len, device, dist=Non
     """Validation mode of SURVEY 8(e)(ii): every rank learns every video's merged-token indices (t*H*W + y1*W + x1, int32),
     for the cross-rank parity check and token-ratio statistics.  Returns int32 [n_videos, max_len], rows padded with -1.
     local_indices: this rank's index tensors, in the order of local_ids.  ONE all-gather of a padded
-    [videos per rank, 1 + max_len] block (column 0 = video id) behind a one-int MAX all-reduce that fixes the block height;
+    [videos per rank, 1 + max_len] block (column 0 = video id) behind a two-int MAX all-reduce that fixes the block height and
+    carries every rank's argument check (an invalid call raises ValueError on ALL ranks instead of hanging the others);
     features never travel."""
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    # Local validation FIRST, and its verdict travels with the block height: a rank that raised before (or between) the
+    # collectives would leave its peers hanging in them.  Cost of the call: two collectives (a two-int MAX all-reduce with one
+    # host sync, then the all-gather).
+    problem = None
     if len(local_ids) != len(local_indices):
-        raise ValueError(f"{len(local_ids)} video ids but {len(local_indices)} index tensors")
+        problem = f"{len(local_ids)} video ids but {len(local_indices)} index tensors"
+    else:
+        for vid, idx in zip(local_ids, local_indices):
+            if idx.numel() > max_len:
+                problem = f"video {vid}: {idx.numel()} indices do not fit max_len={max_len}"
+                break
     # rows per rank = the LARGEST ownership of any rank: cost-balanced sharding (shard_videos(costs=...)) may give one rank
     # more than ceil(n_videos / world) videos, so the ranks agree on the block height with one MAX all-reduce
     per_rank = len(local_ids)
+    failed = 1 if problem else 0
     if world > 1:
-        most = torch.tensor([per_rank], dtype=torch.int32, device=device)
+        most = torch.tensor([per_rank, failed], dtype=torch.int32, device=device)
         dist.all_reduce(most, op=dist.ReduceOp.MAX)
-        per_rank = int(most.item())
+        per_rank, failed = (int(v) for v in most.tolist())
+    if failed:            # on EVERY rank, after the collective
+        raise ValueError(problem or "gather_indices: another rank reported invalid arguments (see its error)")
     block = torch.full((max(per_rank, 1), 1 + max_len), -1, dtype=torch.int32, device=device)
     for k, (vid, idx) in enumerate(zip(local_ids, local_indices)):
-        if idx.numel() > max_len:
-            raise ValueError(f"video {vid}: {idx.numel()} indices do not fit max_len={max_len}")
         block[k, 0] = vid
         block[k, 1:1 + idx.numel()] = idx.to(device=device, dtype=torch.int32)
     if world > 1:

@@ -13,14 +13,10 @@ import torch
 from . import _lib
 
 _DTYPE_CODE = {torch.float32: _lib.STTM_F32, torch.bfloat16: _lib.STTM_BF16, torch.float16: _lib.STTM_F16}
-_pinned_counts = _lib.BoundedCache(16)
-_ws_cache = _lib.BoundedCache(8)      # (device, stream) -> scratch; bounded, see _lib.BoundedCache
 _ws_bytes_cache = {}    # (T, H, W, C, dtype, root_level) -> bytes
-
 
 _seq = [0]
 _seq_lock = threading.Lock()
-_stream_locks = {}          # (device, stream) -> lock: the scratch and the pinned counts of a stream serve ONE call at a time
 
 
 def _next_seq(n=1):
@@ -31,37 +27,11 @@ def _next_seq(n=1):
 
 
 _GUARD_TIMEOUT_S = 120.0
-
-
-def _stream_guard(key):
-    """Two host threads that issue merges on the SAME stream (the default stream of a threaded inference server, say) share
-    that stream's scratch and pinned count buffer: their calls are SERIALISED here -- the scratch is stream-ordered and the
-    pinned counts are consumed before the lock is released, so taking turns is correct.  (Threads on their own streams run
-    concurrently -- tests/test_hip_parity.py.)  A wait longer than _GUARD_TIMEOUT_S raises instead of hanging forever.
-    Lock entries live as long as the stream's scratch does (pruned together with _ws_cache)."""
-    lock = _stream_locks.get(key)
-    if lock is None:
-        with _seq_lock:
-            lock = _stream_locks.setdefault(key, threading.Lock())
-            if len(_stream_locks) > 4 * max(_ws_cache.limit, _pinned_counts.limit):
-                for k in [k for k, l in _stream_locks.items() if k not in _ws_cache and k != key and not l.locked()]:
-                    del _stream_locks[k]
-    if not lock.acquire(timeout=_GUARD_TIMEOUT_S):
-        raise RuntimeError("sttm_amd: waited %.0f s for another host thread inside a merge call on this same stream "
-                           "(give every thread its own torch.cuda.Stream: the scratch and the pinned counts are per stream)"
-                           % _GUARD_TIMEOUT_S)
-    return lock
-
-
-def _counts_host(device, stream_handle, rows=1):
-    """Pinned landing pad of the label stage's counts: one per (device, stream), so callers on different streams
-    (e.g. two host threads) never share one."""
-    key = (device, stream_handle)
-    buf = _pinned_counts.get(key)
-    if buf is None or buf.shape[0] < rows:
-        buf = torch.zeros((max(rows, 16), _lib.CNT_SLOTS), dtype=torch.int32).pin_memory()
-        _pinned_counts[key] = buf
-    return buf
+# host wait for N': a margin over the device-side bound of the fused label stage's grid barrier (2 s), so that a real barrier
+# timeout is READ from the early words (flag bit 31) instead of being pre-empted by the host's own give-up path
+_WAIT_TIMEOUT_US = 2_500_000
+_NO_FUSE_CALLS = 1000       # calls a stream keeps the two-launch label path after one of its barriers timed out, before re-arming
+FLAG_NO_FUSE = 1            # STTM_FLAG_NO_FUSE of include/sttm_hip.h
 
 
 def _channels_last(x):
@@ -88,27 +58,6 @@ def _workspace_bytes(lib, T, H, W, C, dtype, root_level):
     return nbytes
 
 
-def _scratch(dev, stream, nbytes, rows):
-    skey = (dev, stream.cuda_stream)               # scratch is reused call after call on the SAME stream (stream-ordered)
-    cached = _ws_cache.get(skey)
-    if cached is None or cached[0].numel() < nbytes or cached[1].shape[0] < rows:
-        cached = (torch.empty(nbytes, dtype=torch.uint8, device=dev),
-                  torch.empty((max(rows, 16), _lib.CNT_SLOTS), dtype=torch.int32, device=dev))
-        _ws_cache[skey] = cached
-    return cached
-
-
-def _wait(lib, host_row, seq, stream, counts_row):
-    # Output sizes are data dependent, so the host must learn N' -- but only N': the first workgroup of the group-mean kernel
-    # publishes the counts into pinned memory and we wait on that, returning while the feature gather is still running.
-    if lib.sttm_wait_counts(host_row.data_ptr(), seq, 2_000_000) != 0:
-        host_row.copy_(counts_row, non_blocking=True)  # fallback: classic D2H + stream sync
-        stream.synchronize()
-    cnt = host_row.tolist()
-    _check_overflow(cnt[_lib.CNT_OVERFLOW], cnt)
-    return cnt
-
-
 def _check_overflow(ovf, cnt):
     if ovf & _lib.OVF_BARRIER_TIMEOUT:
         raise BarrierTimeout("libsttm_hip: the fused label stage's grid barrier timed out (other streams held the CUs): counts=%s" % (cnt,))
@@ -118,29 +67,39 @@ def _check_overflow(ovf, cnt):
 
 class BarrierTimeout(RuntimeError):
     """The one-launch label stage needs its R column workgroups co-resident; when other work holds the CUs for longer than its
-    2 s bound it gives up and says so.  The wrappers below then switch the process to the two-launch label path (no residency
-    assumption) and repeat the call."""
+    2 s bound it gives up and says so.  The wrappers below repeat THAT call on the two-launch label path (no residency
+    assumption; the `flags` field of the argument block) and keep the calling stream on it for the next _NO_FUSE_CALLS
+    calls -- no process-wide switch is touched, other threads and streams are not affected."""
 
 
-def _retry_without_fused_labels(fn):
-    def wrapped(*a, **kw):
-        try:
-            return fn(*a, **kw)
-        except BarrierTimeout as e:
-            import warnings
-            warnings.warn(str(e) + " -- switching to the two-launch label path (no_fuse=1) and repeating the call")
-            _lib.configure(no_fuse=1)
-            return fn(*a, **kw)
-    wrapped.__name__, wrapped.__doc__ = fn.__name__, fn.__doc__
-    return wrapped
+def _with_barrier_retry(st, fn):
+    """Run fn(flags) for the stream state `st` (whose lock the caller holds); a grid-barrier timeout repeats it once with the
+    two-launch label path."""
+    flags = 0
+    if st.no_fuse_left > 0:
+        st.no_fuse_left -= 1
+        flags = FLAG_NO_FUSE
+    try:
+        return fn(flags)
+    except BarrierTimeout as e:
+        if flags & FLAG_NO_FUSE:
+            raise
+        import warnings
+        warnings.warn(str(e) + " -- repeating the call on the two-launch label path (this stream keeps it for the next "
+                      "%d calls)" % _NO_FUSE_CALLS)
+        st.no_fuse_left = _NO_FUSE_CALLS
+        return fn(FLAG_NO_FUSE)
 
 
 class _StreamState:
-    """Everything one (device, stream) needs call after call: the argument block of sttm_quadtree_merge_packed (only the fields
-    that change are rewritten), the pinned landing pad of N' (classic counts + the early per-column words), scratch."""
-    __slots__ = ("args", "args_ptr", "pinned", "host_ptr", "early_ptr", "host_view", "out2", "out2_ptr", "ws", "counts", "key", "lock")
+    """Everything one (device, stream) needs call after call, for the one-video AND the batch entry point: the argument block
+    of sttm_quadtree_merge_packed (only the fields that change are rewritten), the pinned landing pads of N' (classic counts +
+    the early per-column words; rows for the videos of a batch), scratch, and the ONE lock that serialises host threads which
+    share the stream."""
+    __slots__ = ("args", "args_ptr", "pinned", "host_ptr", "early_ptr", "host_view", "out2", "out2_ptr", "ws", "counts", "key", "lock",
+                 "idx", "handle", "evicted", "no_fuse_left", "batch_pinned", "retired")
 
-    def __init__(self, dev):
+    def __init__(self, idx, handle):
         # one pinned block: int32[8] classic counts, then uint64[EARLY_SLOTS] early words (8-byte aligned at byte 32)
         self.pinned = torch.zeros(4 + _lib.EARLY_SLOTS, dtype=torch.int64).pin_memory()
         self.host_ptr = self.pinned.data_ptr()
@@ -157,37 +116,152 @@ class _StreamState:
         self.counts = None
         self.key = None
         self.lock = threading.Lock()
+        self.idx, self.handle = idx, handle
+        self.evicted = False
+        self.no_fuse_left = 0
+        self.batch_pinned = None        # int32 [rows, CNT_SLOTS] pinned: classic counts of the videos of a batch call
+        self.retired = []               # outgrown pinned pads: kept until this state itself is retired (the stream may still write them)
+
+    def reserve(self, dev, nbytes, rows):
+        """Scratch for `nbytes` and device counts for `rows` videos (grown, never shrunk; allocated on this state's stream, so the
+        caching allocator orders the release of an outgrown block behind the work queued on it)."""
+        if self.ws is None or self.ws.numel() < nbytes:
+            self.ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self.key = None
+        if self.counts is None or self.counts.shape[0] < rows:
+            self.counts = torch.empty((max(rows, 16), _lib.CNT_SLOTS), dtype=torch.int32, device=dev)
+            self.key = None
+
+    def batch_rows(self, rows):
+        if self.batch_pinned is None or self.batch_pinned.shape[0] < rows:
+            if self.batch_pinned is not None:
+                self.retired.append(self.batch_pinned)
+            self.batch_pinned = torch.zeros((max(rows, 32), _lib.CNT_SLOTS), dtype=torch.int32).pin_memory()
+        return self.batch_pinned
+
+    def stream_idle(self):
+        """True when everything queued on this state's stream has completed (its pinned pads are then no longer written)."""
+        try:
+            s = torch.cuda.default_stream(self.idx) if not self.handle else torch.cuda.ExternalStream(self.handle, device=self.idx)
+            return bool(s.query())
+        except Exception:      # noqa: BLE001 -- the stream was destroyed: nothing of it is in flight
+            return True
+
+    def drain(self):
+        try:
+            s = torch.cuda.default_stream(self.idx) if not self.handle else torch.cuda.ExternalStream(self.handle, device=self.idx)
+            s.synchronize()
+        except Exception:      # noqa: BLE001
+            pass
 
 
-_states = _lib.BoundedCache(8)          # (device index, raw stream handle) -> _StreamState
+class _StateCache:
+    """(device index, raw stream handle) -> _StreamState, least-recently-USED first out (a hit refreshes the entry, so the
+    default stream of a long-lived server is not the first to go).  A state whose lock is held -- a thread is inside a call on
+    it -- is never evicted.  An evicted state goes to a graveyard that keeps its pinned pads alive until ITS stream has drained
+    (the group-mean kernel of its last call writes the classic counts after the host has already returned on the early words);
+    nothing blocks and no device-wide synchronisation happens on this path.  Pinning memory and querying streams happen outside
+    the table's lock."""
+
+    def __init__(self, limit=8):
+        import collections
+        import os
+        self.limit = int(os.environ.get("STTM_WS_CACHE", limit))
+        self._d = collections.OrderedDict()
+        self._mu = threading.Lock()
+        self._graveyard = []
+
+    def __len__(self):
+        return len(self._d)
+
+    def __contains__(self, key):
+        return key in self._d
+
+    def graveyard_size(self):
+        return len(self._graveyard)
+
+    def get_or_create(self, idx, handle):
+        key = (idx, handle)
+        with self._mu:
+            st = self._d.get(key)
+            if st is not None:
+                self._d.move_to_end(key)
+                return st
+        fresh = _StreamState(idx, handle)            # pins host memory: outside the lock
+        evicted = []
+        with self._mu:
+            st = self._d.get(key)
+            if st is not None:                       # another thread was faster
+                self._d.move_to_end(key)
+                return st
+            self._d[key] = fresh
+            if len(self._d) > self.limit:
+                for k in list(self._d):
+                    if len(self._d) <= self.limit:
+                        break
+                    cand = self._d[k]
+                    if cand is fresh or not cand.lock.acquire(False):
+                        continue                     # in use right now: the next least-recently-used one goes instead
+                    cand.evicted = True              # a thread that already holds a reference re-resolves its state
+                    del self._d[k]
+                    cand.lock.release()
+                    evicted.append(cand)
+        if evicted:
+            self._retire(evicted)
+        return fresh
+
+    def _retire(self, states):
+        with self._mu:
+            self._graveyard.extend(states)
+            pending = list(self._graveyard)
+        done = [g for g in pending if g.stream_idle()]
+        with self._mu:
+            self._graveyard = [g for g in self._graveyard if g not in done]
+            overflow = self._graveyard[:-32] if len(self._graveyard) > 32 else []
+        for g in overflow:                            # a caller that burns through streams faster than they drain (rare)
+            g.drain()
+        if overflow:
+            with self._mu:
+                self._graveyard = [g for g in self._graveyard if g not in overflow]
+
+
+_states = _StateCache(8)          # (device index, raw stream handle) -> _StreamState
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
 def _state_for(dev, idx, handle):
-    key = (idx, handle)
-    st = _states.get(key)
-    if st is None:
-        with _seq_lock:
-            st = _states.get(key)
-            if st is None:
-                if len(_states) >= _states.limit:
-                    # the oldest state is about to be dropped: its pinned landing pad may still be written by a group-mean kernel
-                    # that is queued or running (the classic counts follow the early words) -- drain the device first (rare path:
-                    # only a caller that keeps creating streams gets here)
-                    torch.cuda.synchronize(dev)
-                st = _StreamState(dev)
-                _states[key] = st
-    return st
+    return _states.get_or_create(idx, handle)
 
 
-@_retry_without_fused_labels
+def _acquire_state(dev):
+    """The state of (current device, current stream) with its lock HELD.  Two host threads that issue merges on the SAME stream
+    (the default stream of a threaded inference server, say) share that stream's scratch and landing pads: their calls are
+    serialised here.  Threads on their own streams run concurrently."""
+    idx = torch.cuda.current_device()
+    handle = _raw_stream(idx) if _raw_stream is not None else torch.cuda.current_stream(dev).cuda_stream
+    while True:
+        st = _states.get_or_create(idx, handle)
+        lock = st.lock
+        if not lock.acquire(False) and not lock.acquire(timeout=_GUARD_TIMEOUT_S):
+            raise RuntimeError("sttm_amd: waited %.0f s for another host thread inside a merge call on this same stream "
+                               "(give every thread its own torch.cuda.Stream: the scratch and the pinned counts are per stream)"
+                               % _GUARD_TIMEOUT_S)
+        if not st.evicted:
+            return st
+        lock.release()              # evicted between the lookup and the lock: resolve again
+
+
 def quadtree_merge_raw(x, threshold, temporal_thresh, root_level, weighted_avg, head_dim, slow_ver=False, return_ctx=False,
-                       feat_dest=None, events=None):
+                       feat_dest=None, events=None, side_tensors=None, side_sum_mode=False):
     """Launch the merge of one video and return the worst-case-sized outputs plus the host counts (only the slots CNT_OUT and
     CNT_OVERFLOW are filled in on the host; the diagnostic counters stay in the device `counts` tensor of the returned context
     and are complete once the stream has drained).
     x: logical [T, C, H, W] CUDA tensor (any strides; channels-last views run zero-copy).
     events: optional _lib.KernelEvents -- the library records them around its kernels (per-kernel timing).
+    side_tensors: optional list of [T, Cv, H, W] tensors (RoPE cos / sin of the position-embedding ablation) pooled over the
+    nodes and groups of THIS merge with sttm_quadtree_apply -- inside the same critical section: the apply reads "the merge that
+    ran last on this stream with this workspace", so no other host thread on the stream may get in between.  Their pooled
+    [T*H*W, Cv] outputs (rows [0, N') valid) are appended to the result as a list.
 
     Host path (round 3): the device chain of one call is ~80 us and the next call cannot be issued before this one knows N', so
     every microsecond between "N' arrived" and "next spatial kernel submitted" is device idle time.  Hence: no device context
@@ -206,87 +280,93 @@ def quadtree_merge_raw(x, threshold, temporal_thresh, root_level, weighted_avg, 
     if idx is None or torch.cuda.current_device() != idx:
         with torch.cuda.device(dev):
             return _merge_on_current_device(x, dtype, threshold, temporal_thresh, root_level, weighted_avg, head_dim, slow_ver,
-                                            return_ctx, feat_dest, events)
+                                            return_ctx, feat_dest, events, side_tensors, side_sum_mode)
     return _merge_on_current_device(x, dtype, threshold, temporal_thresh, root_level, weighted_avg, head_dim, slow_ver,
-                                    return_ctx, feat_dest, events)
+                                    return_ctx, feat_dest, events, side_tensors, side_sum_mode)
 
 
 def _merge_on_current_device(x, dtype, threshold, temporal_thresh, root_level, weighted_avg, head_dim, slow_ver, return_ctx,
-                             feat_dest, events):
+                             feat_dest, events, side_tensors, side_sum_mode):
+    st = _acquire_state(x.device)
+    try:
+        out = _with_barrier_retry(st, lambda flags: _merge_locked(st, x, dtype, threshold, temporal_thresh, root_level, weighted_avg,
+                                                                   head_dim, slow_ver, feat_dest, events, flags))
+        feat, npatch, tlbr, cnt, xc = out
+        ctx = (xc, st.ws, st.counts, dtype, _StreamHandle(st.handle, x.device))
+        sides = None
+        if side_tensors is not None:
+            sides = [_apply_side_tensor(v, ctx, root_level, side_sum_mode) for v in side_tensors]
+    finally:
+        st.lock.release()
+    res = (feat, npatch, tlbr, cnt)
+    if return_ctx:
+        res += (ctx,)
+    if sides is not None:
+        res += (sides,)
+    return res
+
+
+def _merge_locked(st, x, dtype, threshold, temporal_thresh, root_level, weighted_avg, head_dim, slow_ver, feat_dest, events, flags):
+    """One merge on the stream state `st`, whose lock the caller holds."""
     lib = _lib.load()
     dev = x.device
-    idx = torch.cuda.current_device()
-    handle = _raw_stream(idx) if _raw_stream is not None else torch.cuda.current_stream(dev).cuda_stream
-    st = _state_for(dev, idx, handle)
-    lock = st.lock
-    if not lock.acquire(False) and not lock.acquire(timeout=_GUARD_TIMEOUT_S):
-        # (two host threads on the SAME stream share its scratch and landing pad: their calls are serialised)
-        raise RuntimeError("sttm_amd: waited %.0f s for another host thread inside a merge call on this same stream "
-                           "(give every thread its own torch.cuda.Stream: the scratch and the pinned counts are per stream)"
-                           % _GUARD_TIMEOUT_S)
-    try:
-        T, C, H, W = x.shape
+    T, C, H, W = x.shape
+    sT, sC, sH, sW = x.stride()
+    ptr = x.data_ptr()
+    # the production layout is a channels-last VIEW (stride_c == 1); anything else -- or a frame spanning >= 2 GiB, which
+    # the spatial kernel's 32-bit frame offsets cannot address -- gets one transposing copy on the current stream
+    if sC != 1 or (ptr & 15) or ((H - 1) * sH + (W - 1) * sW + C) * x.element_size() >= 2 ** 31:
+        x = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
         sT, sC, sH, sW = x.stride()
         ptr = x.data_ptr()
-        # the production layout is a channels-last VIEW (stride_c == 1); anything else -- or a frame spanning >= 2 GiB, which
-        # the spatial kernel's 32-bit frame offsets cannot address -- gets one transposing copy on the current stream
-        if sC != 1 or (ptr & 15) or ((H - 1) * sH + (W - 1) * sW + C) * x.element_size() >= 2 ** 31:
-            x = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
-            sT, sC, sH, sW = x.stride()
-            ptr = x.data_ptr()
-        head = 0 if head_dim is None else int(head_dim)
-        N = T * H * W
-        a = st.args
-        key = (T, C, H, W, dtype, sT, sH, sW, threshold, temporal_thresh, root_level, weighted_avg, head, slow_ver)
-        if key != st.key:
-            nbytes = _workspace_bytes(lib, T, H, W, C, dtype, root_level)
-            if st.ws is None or st.ws.numel() < nbytes:
-                st.ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-                st.counts = torch.empty((16, _lib.CNT_SLOTS), dtype=torch.int32, device=dev)
-            a.stride_t, a.stride_h, a.stride_w = sT, sH, sW
-            a.T, a.C, a.H, a.W, a.dtype = T, C, H, W, dtype
-            a.threshold, a.temporal_thresh = float(threshold), float(temporal_thresh)
-            a.root_level, a.weighted_avg, a.head_dim, a.slow_ver = int(root_level), int(bool(weighted_avg)), head, int(bool(slow_ver))
-            a.workspace, a.workspace_bytes = st.ws.data_ptr(), st.ws.numel()
-            a.counts = st.counts.data_ptr()
-            a.stream = handle
-            st.key = key
-        if feat_dest is None:
-            feat = torch.empty((N, C), dtype=x.dtype, device=dev)
-        else:
-            # caller-owned destination (fused slice -> merge -> concat): rows [0, N') of it receive the merged features
-            feat = feat_dest
-            if (feat.dim() != 2 or feat.size(1) != C or feat.dtype != x.dtype or feat.device != dev
-                    or not feat.is_contiguous() or feat.data_ptr() % 16):
-                raise ValueError("feat_dest must be a contiguous, 16-byte aligned [rows, C] tensor of the input's dtype and device")
-        npatch = torch.empty(N, dtype=torch.int32, device=dev)
-        tlbr = torch.empty((N, 5), dtype=torch.int32, device=dev)
-        seq = _next_seq()
-        a.x, a.feat_out, a.npatch_out, a.tlbr_out, a.seq = ptr, feat.data_ptr(), npatch.data_ptr(), tlbr.data_ptr(), seq
-        a.events = events.pointer() if events is not None else None
-        rc = lib.sttm_quadtree_merge_packed(st.args_ptr)
-        if rc < 0:
-            st.key = None
-            _lib.raise_for(rc)
-        # Output sizes are data dependent, so the host must learn N' -- but only N': every column of the label stage reports its
-        # survivors into pinned memory as its last action (fallback: the group-mean kernel's first workgroup publishes the counts)
-        # and we wait on that, returning while the feature gather is still running.
-        if lib.sttm_wait_counts_early(st.host_ptr, st.early_ptr, a.n_early, seq, 2_000_000, st.out2_ptr) != 0:
-            stream = torch.cuda.current_stream(dev)
-            st.host_view.copy_(st.counts[0], non_blocking=True)  # fallback: classic D2H + stream sync
-            stream.synchronize()
-            h = st.host_view.tolist()
-            st.out2[0], st.out2[1] = h[_lib.CNT_OUT], h[_lib.CNT_OVERFLOW]
-        n_out, ovf = st.out2[0], st.out2[1]
-        cnt = [0] * _lib.CNT_SLOTS
-        cnt[_lib.CNT_OUT], cnt[_lib.CNT_OVERFLOW] = n_out, ovf
-        if ovf:
-            _check_overflow(ovf, cnt)
-    finally:
-        lock.release()
-    if return_ctx:
-        return feat, npatch, tlbr, cnt, (x, st.ws, st.counts, dtype, _StreamHandle(handle, dev))
-    return feat, npatch, tlbr, cnt
+    head = 0 if head_dim is None else int(head_dim)
+    N = T * H * W
+    a = st.args
+    key = (T, C, H, W, dtype, sT, sH, sW, threshold, temporal_thresh, root_level, weighted_avg, head, slow_ver)
+    if key != st.key:
+        nbytes = _workspace_bytes(lib, T, H, W, C, dtype, root_level)
+        st.reserve(dev, nbytes, 16)
+        a.stride_t, a.stride_h, a.stride_w = sT, sH, sW
+        a.T, a.C, a.H, a.W, a.dtype = T, C, H, W, dtype
+        a.threshold, a.temporal_thresh = float(threshold), float(temporal_thresh)
+        a.root_level, a.weighted_avg, a.head_dim, a.slow_ver = int(root_level), int(bool(weighted_avg)), head, int(bool(slow_ver))
+        a.workspace, a.workspace_bytes = st.ws.data_ptr(), st.ws.numel()
+        a.counts = st.counts.data_ptr()
+        a.stream = st.handle
+        st.key = key
+    if feat_dest is None:
+        feat = torch.empty((N, C), dtype=x.dtype, device=dev)
+    else:
+        # caller-owned destination (fused slice -> merge -> concat): rows [0, N') of it receive the merged features
+        feat = feat_dest
+        if (feat.dim() != 2 or feat.size(1) != C or feat.dtype != x.dtype or feat.device != dev
+                or not feat.is_contiguous() or feat.data_ptr() % 16):
+            raise ValueError("feat_dest must be a contiguous, 16-byte aligned [rows, C] tensor of the input's dtype and device")
+    npatch = torch.empty(N, dtype=torch.int32, device=dev)
+    tlbr = torch.empty((N, 5), dtype=torch.int32, device=dev)
+    seq = _next_seq()
+    a.x, a.feat_out, a.npatch_out, a.tlbr_out, a.seq = ptr, feat.data_ptr(), npatch.data_ptr(), tlbr.data_ptr(), seq
+    a.events = events.pointer() if events is not None else None
+    a.flags = flags
+    rc = lib.sttm_quadtree_merge_packed(st.args_ptr)
+    if rc < 0:
+        st.key = None
+        _lib.raise_for(rc)
+    # Output sizes are data dependent, so the host must learn N' -- but only N': every column of the label stage reports its
+    # survivors into pinned memory as its last action (fallback: the group-mean kernel's first workgroup publishes the counts)
+    # and we wait on that, returning while the feature gather is still running.
+    if lib.sttm_wait_counts_early(st.host_ptr, st.early_ptr, a.n_early, seq, _WAIT_TIMEOUT_US, st.out2_ptr) != 0:
+        stream = torch.cuda.current_stream(dev)
+        st.host_view.copy_(st.counts[0], non_blocking=True)  # fallback: classic D2H + stream sync
+        stream.synchronize()
+        h = st.host_view.tolist()
+        st.out2[0], st.out2[1] = h[_lib.CNT_OUT], h[_lib.CNT_OVERFLOW]
+    n_out, ovf = st.out2[0], st.out2[1]
+    cnt = [0] * _lib.CNT_SLOTS
+    cnt[_lib.CNT_OUT], cnt[_lib.CNT_OVERFLOW] = n_out, ovf
+    if ovf:
+        _check_overflow(ovf, cnt)
+    return feat, npatch, tlbr, cnt, x
 
 
 class _StreamHandle:
@@ -313,7 +393,6 @@ def _apply_side_tensor(v, ctx, root_level, sum_mode):
     return out
 
 
-@_retry_without_fused_labels
 def get_quadtree_features_batch(videos, threshold, temporal_thresh=-1.0, root_level=0, weighted_avg=False,
                                 slow_ver=False, head_dim=None, events=None):
     """Extension (not in the reference, whose API is one video per call): merge a LIST of videos and return the list of
@@ -322,65 +401,95 @@ def get_quadtree_features_batch(videos, threshold, temporal_thresh=-1.0, root_le
     Videos of one shape / dtype / stride set go through sttm_quadtree_merge_batch together: every kernel gets a second grid
     dimension over the videos, so the launch ramps and tails and the latency-bound label stage of one video overlap the
     bandwidth-bound kernels of its neighbours -- on the caller's own stream, with no side streams.  The host waits for the
-    per-video token counts only after everything has been enqueued."""
+    per-video token counts only after everything has been enqueued.  Same per-stream state (lock, scratch, landing pads) as
+    the one-video call."""
     if not videos:
         return []
-    lib = _lib.load()
     dev = videos[0].device
     if not all(v.is_cuda and v.device == dev for v in videos):
         raise RuntimeError("sttm_amd runs on the GPU only: every video must be a CUDA (ROCm) tensor on one device; "
                            "there is no CPU fallback")
+    with torch.cuda.device(dev):
+        st = _acquire_state(dev)
+        try:
+            return _with_barrier_retry(st, lambda flags: _batch_locked(st, videos, dev, threshold, temporal_thresh, root_level,
+                                                                        weighted_avg, slow_ver, head_dim, events, flags))
+        finally:
+            st.lock.release()
+
+
+def _batch_locked(st, videos, dev, threshold, temporal_thresh, root_level, weighted_avg, slow_ver, head_dim, events, flags):
+    lib = _lib.load()
     head = 0 if head_dim is None else int(head_dim)
     out = [None] * len(videos)
-    with torch.cuda.device(dev):
-        stream = torch.cuda.current_stream(dev)
-        guard = _stream_guard((dev, stream.cuda_stream))
-        try:
-            groups = {}
-            vids = []
-            for j, x in enumerate(videos):
-                if x.dim() != 4 or x.dtype not in _DTYPE_CODE:
-                    raise ValueError("expected [T, C, H, W] float32 / bfloat16 / float16 tensors")
-                x = _channels_last(x)
-                vids.append(x)
-                groups.setdefault((tuple(x.shape), x.dtype, tuple(x.stride())), []).append(j)
-            pend = []
-            rows_used = 0
-            total = len(videos)
-            host = _counts_host(dev, stream.cuda_stream, total)
-            # one workspace block per video of the call (all groups): sized for the largest
-            per_video = 0
-            for (shape, dt, _), ids in groups.items():
-                T, C, H, W = shape
-                per_video = max(per_video, _workspace_bytes(lib, T, H, W, C, _DTYPE_CODE[dt], root_level))
-            per_video = (per_video + 255) // 256 * 256
-            ws, counts = _scratch(dev, stream, per_video * total, total)
-            for (shape, dt, strides), ids in groups.items():
-                T, C, H, W = shape
-                N = T * H * W
-                n = len(ids)
-                feats = [torch.empty((N, C), dtype=dt, device=dev) for _ in ids]
-                npatches = [torch.empty(N, dtype=torch.int32, device=dev) for _ in ids]
-                tlbrs = [torch.empty((N, 5), dtype=torch.int32, device=dev) for _ in ids]
-                arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])      # noqa: E731
-                seq = _next_seq(n)
-                rc = lib.sttm_quadtree_merge_batch(
-                    n, arr([vids[j] for j in ids]), strides[0], strides[1], strides[2], strides[3], T, C, H, W, _DTYPE_CODE[dt],
-                    float(threshold), float(temporal_thresh), int(root_level), int(bool(weighted_avg)), head, int(bool(slow_ver)),
-                    ws.data_ptr() + rows_used * per_video, per_video, arr(feats), arr(npatches), arr(tlbrs),
-                    counts[rows_used].data_ptr(), host[rows_used].data_ptr(), seq,
-                    events.pointer() if events is not None else None, stream.cuda_stream)
-                _lib.raise_for(rc)
-                for k, j in enumerate(ids):
-                    pend.append((j, feats[k], npatches[k], tlbrs[k], seq + k, rows_used + k))
-                rows_used += n
-            for j, feat, npatch, tlbr, seq, row in pend:
-                cnt = _wait(lib, host[row], seq, stream, counts[row])
-                n_out = cnt[_lib.CNT_OUT]
-                out[j] = (feat[:n_out], npatch[:n_out], tlbr[:n_out])
-        finally:
-            guard.release()
+    groups = {}
+    vids = []
+    for j, x in enumerate(videos):
+        if x.dim() != 4 or x.dtype not in _DTYPE_CODE:
+            raise ValueError("expected [T, C, H, W] float32 / bfloat16 / float16 tensors")
+        x = _channels_last(x)
+        vids.append(x)
+        groups.setdefault((tuple(x.shape), x.dtype, tuple(x.stride())), []).append(j)
+    pend = []
+    rows_used = 0
+    total = len(videos)
+    # one workspace block per video of the call (all groups): sized for the largest
+    per_video = 0
+    for (shape, dt, _), ids in groups.items():
+        T, C, H, W = shape
+        per_video = max(per_video, _workspace_bytes(lib, T, H, W, C, _DTYPE_CODE[dt], root_level))
+    per_video = (per_video + 255) // 256 * 256
+    st.reserve(dev, per_video * total, total)
+    host = st.batch_rows(total)
+    ws, counts = st.ws, st.counts
+    for (shape, dt, strides), ids in groups.items():
+        T, C, H, W = shape
+        N = T * H * W
+        n = len(ids)
+        feats = [torch.empty((N, C), dtype=dt, device=dev) for _ in ids]
+        npatches = [torch.empty(N, dtype=torch.int32, device=dev) for _ in ids]
+        tlbrs = [torch.empty((N, 5), dtype=torch.int32, device=dev) for _ in ids]
+        arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])      # noqa: E731
+        seq = _next_seq(n)
+        rc = lib.sttm_quadtree_merge_batch(
+            n, arr([vids[j] for j in ids]), strides[0], strides[1], strides[2], strides[3], T, C, H, W, _DTYPE_CODE[dt],
+            float(threshold), float(temporal_thresh), int(root_level), int(bool(weighted_avg)), head, int(bool(slow_ver)),
+            ws.data_ptr() + rows_used * per_video, per_video, arr(feats), arr(npatches), arr(tlbrs),
+            counts[rows_used].data_ptr(), host[rows_used].data_ptr(), seq,
+            events.pointer() if events is not None else None, st.handle, flags)
+        _lib.raise_for(rc)
+        for k, j in enumerate(ids):
+            pend.append((j, feats[k], npatches[k], tlbrs[k], seq + k, rows_used + k))
+        rows_used += n
+    for j, feat, npatch, tlbr, seq, row in pend:
+        # N' of every video from pinned memory (published by the group-mean kernel's first workgroup), no stream synchronisation
+        if lib.sttm_wait_counts(host[row].data_ptr(), seq, _WAIT_TIMEOUT_US) != 0:
+            host[row].copy_(counts[row], non_blocking=True)  # fallback: classic D2H + stream sync
+            torch.cuda.current_stream(dev).synchronize()
+        cnt = host[row].tolist()
+        _check_overflow(cnt[_lib.CNT_OVERFLOW], cnt)
+        n_out = cnt[_lib.CNT_OUT]
+        out[j] = _sized(feat, npatch, tlbr, n_out)
     return out
+
+
+_exact_outputs = [bool(int(__import__("os").environ.get("STTM_EXACT_OUTPUTS", "0")))]
+
+
+def set_exact_outputs(flag):
+    """Opt-in compaction.  N' is only known after the kernels have run, so the outputs are allocated for the worst case
+    ([T*H*W, C]: 103 MB for 46 MB used at the 128-frame headline, 578 MB at T=180 C=8192 bf16) and returned as leading VIEWS --
+    the whole block stays alive as long as the caller holds the result.  With exact outputs the three results are copied into
+    exact-size tensors (one extra read + write of N' rows, stream-ordered) and the worst-case block goes back to the caching
+    allocator at once, like the reference's exact-size returns (quadtree_builder.py:198-226).  The copy-free alternative is
+    get_quadtree_features_into (the caller owns the destination).  Also settable with STTM_EXACT_OUTPUTS=1."""
+    _exact_outputs[0] = bool(flag)
+
+
+def _sized(feat, npatch, tlbr, n, owned=True):
+    if _exact_outputs[0] and owned:
+        return feat[:n].clone(), npatch[:n].clone(), tlbr[:n].clone()
+    return feat[:n], npatch[:n], tlbr[:n]
 
 
 def get_quadtree_features(_video_feature, threshold, temporal_thresh=-1.0, root_level=0, weighted_avg=False,
@@ -395,21 +504,23 @@ def get_quadtree_features(_video_feature, threshold, temporal_thresh=-1.0, root_
     if pos_embs is None:
         feat, npatch, tlbr, cnt = quadtree_merge_raw(_video_feature, threshold, temporal_thresh, root_level,
                                                      weighted_avg, head_dim, slow_ver)
-        n = cnt[_lib.CNT_OUT]
-        return feat[:n], npatch[:n], tlbr[:n]
+        return _sized(feat, npatch, tlbr, cnt[_lib.CNT_OUT])
     # position-embedding ablation (quadtree_attn_monkey_patch_for_abl_pos.py): cos / sin ride along the same tree
     cos, sin = pos_embs
     if temporal_thresh <= 0 and not pos_emb_weighted_avg:
         # quirk Q11 of the reference: `pos_embs_cos` is only assigned on the temporal or the weighted path
         raise UnboundLocalError("local variable 'pos_embs_cos' referenced before assignment (reference behaviour for "
                                 "pos_embs with temporal_thresh <= 0 and pos_emb_weighted_avg=False)")
-    feat, npatch, tlbr, cnt, ctx = quadtree_merge_raw(_video_feature, threshold, temporal_thresh, root_level,
-                                                      weighted_avg, head_dim, slow_ver, return_ctx=True)
+    # the merge and the two poolings that read its node / group tables run under ONE hold of the stream's lock
+    feat, npatch, tlbr, cnt, (out_cos, out_sin) = quadtree_merge_raw(
+        _video_feature, threshold, temporal_thresh, root_level, weighted_avg, head_dim, slow_ver,
+        side_tensors=[cos, sin], side_sum_mode=pos_emb_weighted_avg)
     n = cnt[_lib.CNT_OUT]
-    out_cos = _apply_side_tensor(cos, ctx, root_level, pos_emb_weighted_avg)
-    out_sin = _apply_side_tensor(sin, ctx, root_level, pos_emb_weighted_avg)
-    return feat[:n], npatch[:n], tlbr[:n], (out_cos[:n], out_sin[:n])
-
+    if _exact_outputs[0]:
+        out_cos, out_sin = out_cos[:n].clone(), out_sin[:n].clone()
+    else:
+        out_cos, out_sin = out_cos[:n], out_sin[:n]
+    return _sized(feat, npatch, tlbr, n) + ((out_cos, out_sin),)
 
 
 def get_quadtree_features_into(dest, _video_feature, threshold, temporal_thresh=-1.0, root_level=0, weighted_avg=False,
@@ -426,4 +537,6 @@ def get_quadtree_features_into(dest, _video_feature, threshold, temporal_thresh=
     feat, npatch, tlbr, cnt = quadtree_merge_raw(_video_feature, threshold, temporal_thresh, root_level, weighted_avg,
                                                  head_dim, slow_ver, feat_dest=dest)
     n = cnt[_lib.CNT_OUT]
+    if _exact_outputs[0]:
+        return feat[:n], npatch[:n].clone(), tlbr[:n].clone()        # (the features already live in the caller's buffer)
     return feat[:n], npatch[:n], tlbr[:n]

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"libsttm_hip.so does not export {n}"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
-    assert lib.sttm_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.sttm_abi_version() == _lib.ABI_VERSION == 6
 
 
 @pytest.mark.parametrize("H,W", [(14, 14), (27, 27), (20, 36), (18, 26), (13, 24), (16, 22), (10, 30), (7, 7),
@@ -149,34 +149,80 @@ def test_feature_file_loaders_refuse_the_cpu(tmp_path):
         load_qwen2vl_features(str(p), "cuda:0")              # a [T, tokens, C] file is not the Qwen2-VL [T, H, W, C] format
 
 
-def test_barrier_timeout_switches_to_the_two_launch_label_path(monkeypatch):
-    """Host logic of the round-2 advisor finding: a timed-out grid barrier of the fused label stage is reported through its own
-    bit of the overflow slot (include/sttm_hip.h: STTM_OVF_BARRIER_TIMEOUT) and the wrapper repeats the call with no_fuse=1."""
+def test_barrier_timeout_repeats_the_call_on_the_two_launch_label_path():
+    """Host logic: a timed-out grid barrier of the fused label stage is reported through its own bit of the overflow slot
+    (include/sttm_hip.h: STTM_OVF_BARRIER_TIMEOUT) and the wrapper repeats THAT call with STTM_FLAG_NO_FUSE in its argument
+    block; the stream keeps the two-launch path for a bounded number of calls and then re-arms.  No process-wide switch
+    (sttm_configure) is touched: other threads' calls are not affected (round-3 review item)."""
     import warnings
     from sttm_amd import quadtree_interface as QI
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "sttm_hip.h")).read()
     assert re.search(r"#define\s+STTM_OVF_BARRIER_TIMEOUT\s+64\b", hdr) and _lib.OVF_BARRIER_TIMEOUT == 64
-    configured = []
-    monkeypatch.setattr(_lib, "configure", lambda **kw: configured.append(kw))
+    assert re.search(r"#define\s+STTM_FLAG_NO_FUSE\s+1\b", hdr) and QI.FLAG_NO_FUSE == 1
+
+    class St:                   # the two fields of a stream state the retry logic uses
+        no_fuse_left = 0
+    st = St()
     calls = []
 
-    @QI._retry_without_fused_labels
-    def merge(x):
-        calls.append(x)
+    def merge(flags):
+        calls.append(flags)
         if len(calls) == 1:
             raise QI.BarrierTimeout("timed out")
-        return x + 1
+        return 42
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
-        assert merge(41) == 42
-    assert calls == [41, 41] and configured == [{"no_fuse": 1}] and w and "two-launch" in str(w[0].message)
+        assert QI._with_barrier_retry(st, merge) == 42
+    assert calls == [0, QI.FLAG_NO_FUSE] and w and "two-launch" in str(w[0].message)
+    assert st.no_fuse_left == QI._NO_FUSE_CALLS
+    assert QI._with_barrier_retry(st, merge) == 42 and calls[-1] == QI.FLAG_NO_FUSE and st.no_fuse_left == QI._NO_FUSE_CALLS - 1
+    st.no_fuse_left = 0                                   # ... and the stream re-arms the fused path afterwards
+    assert QI._with_barrier_retry(st, merge) == 42 and calls[-1] == 0
 
-    @QI._retry_without_fused_labels
-    def overflow(x):
+    def overflow(flags):
         raise RuntimeError("internal list overflow")
     with pytest.raises(RuntimeError):
-        overflow(1)                      # any other failure is not retried
-    assert configured == [{"no_fuse": 1}]
+        QI._with_barrier_retry(st, overflow)            # any other failure is not retried
+
+    def always(flags):
+        raise QI.BarrierTimeout("again")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with pytest.raises(QI.BarrierTimeout):
+            QI._with_barrier_retry(st, always)          # a timeout on the two-launch path itself is not retried again
+
+
+def test_stream_state_cache_is_lru_and_never_evicts_a_state_in_use(monkeypatch):
+    """Round-3 advisor finding: per-(device, stream) state must go out least-recently-USED first (a hit refreshes the entry), a state
+    whose lock is held must stay, and an evicted state is parked until its stream has drained instead of being dropped while the
+    group-mean kernel may still write its pinned landing pad."""
+    import threading
+    from sttm_amd import quadtree_interface as QI
+
+    class FakeState:
+        def __init__(self, idx, handle):
+            self.idx, self.handle, self.lock, self.evicted, self.idle = idx, handle, threading.Lock(), False, False
+
+        def stream_idle(self):
+            return self.idle
+
+        def drain(self):
+            self.idle = True
+    monkeypatch.setattr(QI, "_StreamState", FakeState)
+    c = QI._StateCache(3)
+    c.limit = 3
+    s = [c.get_or_create(0, h) for h in (10, 11, 12)]
+    assert c.get_or_create(0, 10) is s[0]                 # a hit: handle 10 is now the most recently used
+    c.get_or_create(0, 13)
+    assert (0, 11) not in c and (0, 10) in c and len(c) == 3 and s[1].evicted       # 11 was the least recently used
+    assert c.graveyard_size() == 1                        # ... and waits for its stream (FakeState.idle is False)
+    s[2].lock.acquire()                                   # a thread is inside a call on handle 12 (now the least recently used)
+    c.get_or_create(0, 14)
+    assert (0, 12) in c and not s[2].evicted and (0, 10) not in c and len(c) == 3
+    s[2].lock.release()
+    s[1].idle = s[0].idle = True                          # their streams drained: the next retirement sweep lets them go
+    c.get_or_create(0, 15)
+    assert c.graveyard_size() == 1 and (0, 12) not in c   # only the state evicted just now is still parked
 
 
 def test_build_tag_depends_on_the_compile_flags():
@@ -186,7 +232,7 @@ def test_build_tag_depends_on_the_compile_flags():
 
 
 def test_argument_block_matches_the_header_and_rejects_null():
-    """ABI v5: the ctypes mirror of sttm_merge_args has the header's fields in the header's order, the packed entry point and
+    """ABI v5 / v6: the ctypes mirror of sttm_merge_args has the header's fields in the header's order, the packed entry point and
     the early wait validate their arguments without a GPU, and the early wait adds up column words the way the kernels write them."""
     import ctypes
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "sttm_hip.h")).read()

@@ -67,6 +67,18 @@ def test_one_rank_torchrun_through_both_collectives(tmp_path):
     assert r.returncode == 0 and "DIST_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+def test_two_ranks_over_rccl_when_the_box_has_two_gpus(tmp_path):
+    """The same worker with WORLD_SIZE 2, one rank per GPU, nccl = RCCL over xGMI: gather_counts / gather_indices with the HIP
+    merge on both devices.  Runs wherever the box exposes >= 2 GPUs (the driver's multi-GPU node); skipped on 1-GPU boxes."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (one rank per GPU)")
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    r = _torchrun(2, [str(script)])
+    assert r.returncode == 0 and r.stdout.count("DIST_OK") == 2, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 def test_bench_validate_mode_under_torchrun():
     """bench.py as the driver launches it (torchrun, one rank here), small sizes, with the index gather of --validate."""
     r = _torchrun(1, [os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--videos-per-step", "8", "--frames", "16",

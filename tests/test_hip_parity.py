@@ -108,6 +108,8 @@ ORACLE_CASES = [
     (128, 1024, 14, 14, 30, torch.float32, 0.85, 0.55, 1, False),  # C3: Video-MME 128 frames (run_vidqa.sh:58)
     (128, 1024, 14, 14, 31, torch.float32, 0.80, 0.50, 1, False),  # headline size, varied tree structure (73-115 nodes / frame)
     (128, 1024, 13, 24, 32, torch.float32, 0.85, 0.60, 1, False),  # C4: Qwen2-VL grid, full length (run_vidqa.sh:84)
+    (128, 1024, 20, 36, 44, torch.float32, 0.85, 0.60, 1, False),  # C4: the 4-level grids at full length too
+    (128, 1024, 18, 26, 45, torch.float32, 0.85, 0.60, 1, False),
     (180, 1024, 14, 14, 33, torch.float32, 0.94, 0.82, 1, False),  # C5: MLVU 180 frames (run_vidqa.sh:89)
     (180, 1024, 14, 14, 34, torch.bfloat16, 0.94, 0.82, 1, False),
     (4200, 16, 14, 14, 35, torch.float32, 0.85, 0.55, 1, False),   # 67 200 label slots per column: past the 16-bit slot ids of round 1
@@ -220,7 +222,7 @@ def test_label_stage_paths_give_identical_results(opts):
     from oracle import sttm_oracle as O
     from sttm_amd import _lib, get_quadtree_features
     from sttm_amd.synth import synth_video
-    defaults = dict(fold_labels=0, no_fuse=0, force_gmem_labels=0, fold_kb=64, pairs_seg=0, pairs_nt=0, pairs_var=0, no_dense=0)
+    defaults = dict(fold_labels=0, no_fuse=0, force_gmem_labels=0, fold_kb=64, pairs_seg=0, pairs_nt=0, pairs_var=0, no_dense=0, k1_var=0)
     try:
         _lib.configure(**opts)
         for path in case_paths(["st_"]):
@@ -277,6 +279,54 @@ def test_same_stream_from_two_threads_is_serialised_not_raced():
             get_quadtree_features(x, 0.85, 0.55, 1)
     torch.cuda.synchronize()
     assert len(QI._states) <= QI._states.limit           # per-stream state (scratch, pinned landing pad, lock) is bounded
+    assert QI._states.graveyard_size() <= 33             # evicted states wait for their streams, in bounded numbers
+    assert all(torch.equal(a, b) for a, b in zip(get_quadtree_features(x, 0.85, 0.55, 1), ref))
+
+
+def test_pos_embs_from_two_threads_on_one_stream():
+    """Round-3 review item: sttm_quadtree_apply reads "the merge that ran last on this stream with this workspace", so the merge
+    and the two poolings of a pos_embs call must sit in ONE critical section.  Two host threads hammer the same stream -- one with
+    pos_embs, one with plain merges of a DIFFERENT clip (which rewrite the node / group tables) -- and every pos_embs result must
+    equal the single-threaded one."""
+    import threading
+    from sttm_amd import get_quadtree_features
+    from sttm_amd.synth import synth_video
+    dev = _dev()
+    xa = synth_video(12, 128, 14, 14, seed=51).to(dev)
+    xb = synth_video(12, 128, 14, 14, seed=52, c=0.15, p_static=0.7).to(dev)
+    g = torch.Generator().manual_seed(5)
+    cos = torch.randn(12, 64, 14, 14, generator=g).to(dev)
+    sin = torch.randn(12, 64, 14, 14, generator=g).to(dev)
+    ref = get_quadtree_features(xa, 0.85, 0.55, 1, pos_embs=(cos, sin), pos_emb_weighted_avg=True)
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream(dev)
+    stop, errs, got = threading.Event(), [], []
+
+    def plain():
+        try:
+            with torch.cuda.stream(stream):
+                while not stop.is_set():
+                    get_quadtree_features(xb, 0.80, 0.50, 1)
+        except Exception as e:      # noqa: BLE001
+            errs.append(repr(e))
+
+    def with_pos():
+        try:
+            with torch.cuda.stream(stream):
+                for _ in range(60):
+                    got.append(get_quadtree_features(xa, 0.85, 0.55, 1, pos_embs=(cos, sin), pos_emb_weighted_avg=True))
+        except Exception as e:      # noqa: BLE001
+            errs.append(repr(e))
+    ta, tb = threading.Thread(target=plain), threading.Thread(target=with_pos)
+    ta.start(); tb.start()
+    tb.join(120)
+    stop.set()
+    ta.join(30)
+    torch.cuda.synchronize()
+    assert not errs and len(got) == 60
+    for out in got:
+        assert all(torch.equal(a, b) for a, b in zip(out[:3], ref[:3]))
+        assert torch.equal(out[3][0], ref[3][0]) and torch.equal(out[3][1], ref[3][1])
 
 
 def test_batched_extension_equals_per_video_calls():

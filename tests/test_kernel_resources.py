@@ -1,0 +1,83 @@
+"""Register-allocation guard (CPU): the kernel descriptors of the BUILT library, read out of its embedded gfx950 code objects.
+
+The instantiations that the BASELINE.json configurations and the production shapes launch must not use scratch memory
+(`private_segment_fixed_size == 0`): a spilled value sits on the critical path of these latency-bound kernels and enabling the
+private segment costs every wave of the launch ("any scratch use is poison").  The list is by mangled-name
+fragment; a listed kernel that is missing from the library fails too, so a renamed template cannot silently drop out.
+"""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+# (what it is, regex on the mangled kernel name)
+NO_SCRATCH = [
+    ("K1 headline / C2 / C3 / C5: fp32 C=1024, 3-level tree", r"k_spatialIfLi4ELi3ELi0ELi256ELb0E"),
+    ("K1 production: bf16 C=3584, 32-byte packs", r"k_spatialINS_6bf16_tELi16ELi3ELi0ELi256ELb0E"),
+    ("K1 72B width: bf16 C=8192, 16-byte packs, 1024 threads", r"k_spatialINS_6bf16_tELi8ELi3ELi0ELi1024ELb0E"),
+    ("K1 bf16 C<=2048", r"k_spatialINS_6bf16_tELi8ELi3ELi0ELi256ELb0E"),
+    ("K1 fp16 C<=2048", r"k_spatialINS_5f16_tELi8ELi3ELi0ELi256ELb0E"),
+    ("K1 C4 grids (20x36, 18x26): fp32 4-level tree", r"k_spatialIfLi4ELi3ELi1ELi256ELb0E"),
+    ("K2 fp32 (8-wide row packs)", r"k_pairs256IfLi8ELi5ELi32E"),
+    ("K2 bf16", r"k_pairs256INS_6bf16_tELi8ELi5ELi64E"),
+    ("K3 fused label stage", r"k_col_labelsILi2E"),
+    ("K5 fp32", r"k_group_meanIfLi8ELi6E"),
+    ("K5 bf16", r"k_group_meanINS_6bf16_tELi8ELi6E"),
+    ("ToMe 256-tile match, fp32 two-plane", r"k_tome_match_gldsILi2ELi4E"),
+    ("ToMe 256-tile match, one plane", r"k_tome_match_gldsILi1ELi1E"),
+]
+
+
+def _kernels_of(lib):
+    """{mangled name: (private_segment_fixed_size, vgpr_count)} of every kernel in the library's gfx950 code objects."""
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        fat = os.path.join(tmp, "fat.bin")
+        subprocess.run([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", lib, os.path.join(tmp, "copy.so")], check=True)
+        blob = open(fat, "rb").read()
+        starts = [m.start() for m in re.finditer(re.escape(MAGIC), blob)]
+        for n, s in enumerate(starts):
+            e = starts[n + 1] if n + 1 < len(starts) else len(blob)
+            part = os.path.join(tmp, f"b{n}.bin")
+            with open(part, "wb") as fh:
+                fh.write(blob[s:e])
+            co = os.path.join(tmp, f"b{n}.co")
+            r = subprocess.run([f"{LLVM}/clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                                f"--input={part}", f"--output={co}", "--unbundle"], capture_output=True, text=True)
+            if r.returncode != 0 or not os.path.exists(co) or os.path.getsize(co) == 0:
+                continue
+            notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], capture_output=True, text=True, check=True).stdout
+            for blk in notes.split("- .agpr_count:")[1:]:
+                name = re.search(r"\.name:\s+(\S+)", blk)
+                priv = re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk)
+                vg = re.search(r"\.vgpr_count:\s+(\d+)", blk)
+                if name and priv:
+                    out[name.group(1)] = (int(priv.group(1)), int(vg.group(1)) if vg else -1)
+    return out
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sttm_amd", "lib", "libsttm_hip.so")
+    if not os.path.exists(lib):
+        pytest.skip("library not built")
+    for tool in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf"):
+        if not os.path.exists(f"{LLVM}/{tool}") and not shutil.which(tool):
+            pytest.skip(f"{tool} not available")
+    k = _kernels_of(lib)
+    assert len(k) > 50, "could not read the kernel descriptors of the library"
+    return k
+
+
+@pytest.mark.parametrize("what,pattern", NO_SCRATCH, ids=[w for w, _ in NO_SCRATCH])
+def test_headline_and_production_kernels_use_no_scratch(kernels, what, pattern):
+    hits = {n: v for n, v in kernels.items() if re.search(pattern, n)}
+    assert hits, f"no kernel matches {pattern!r} ({what}): the guard list is stale"
+    spilled = {n: v for n, v in hits.items() if v[0] != 0}
+    assert not spilled, f"{what}: scratch in use (bytes per lane, VGPRs): {spilled}"

@@ -81,6 +81,33 @@ def test_cost_balanced_sharding_through_the_index_gather(tmp_path):
         assert torch.equal(torch.load(os.path.join(str(tmp_path), f"i{r}.pt")), expect_idx)
 
 
+def _bad_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # rank 1 passes an index tensor longer than max_len; rank 0's arguments are fine
+    idx = [torch.arange(20 if rank == 1 else 4, dtype=torch.int32)]
+    try:
+        gather_indices([rank], idx, 2, 8, torch.device("cpu"), dist)
+        verdict = "returned"
+    except ValueError as e:
+        verdict = "ValueError: " + str(e)
+    with open(os.path.join(out_dir, f"v{rank}.txt"), "w") as fh:
+        fh.write(verdict)
+    dist.barrier()                 # both ranks are still in step: nobody is stuck inside a collective
+    dist.destroy_process_group()
+
+
+def test_invalid_arguments_on_one_rank_raise_on_every_rank(tmp_path):
+    """Round-3 advisor finding: a rank that raised before / between the two collectives of gather_indices left its peers hanging.
+    The argument check now travels with the MAX all-reduce and every rank raises after it."""
+    mp.spawn(_bad_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    v0 = open(os.path.join(str(tmp_path), "v0.txt")).read()
+    v1 = open(os.path.join(str(tmp_path), "v1.txt")).read()
+    assert v0.startswith("ValueError") and "another rank" in v0
+    assert v1.startswith("ValueError") and "do not fit max_len" in v1
+
+
 def test_gather_indices_rejects_mismatched_lists():
     with pytest.raises(ValueError):
         gather_indices([0, 1], [torch.zeros(3, dtype=torch.int32)], 2, 8, torch.device("cpu"))
