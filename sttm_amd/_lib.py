@@ -8,7 +8,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # STTM_LIB=dev selects the development build (python -m sttm_amd.build --dev: measurement hooks for tools/, never the product)
-LIB_PATH = os.path.join(_HERE, "lib", "libsttm_hip_dev.so" if os.environ.get("STTM_LIB") == "dev" else "libsttm_hip.so")
+# (any other value of STTM_LIB = the file name of another build under sttm_amd/lib/: same-box A/B of two builds in tools/)
+_which = os.environ.get("STTM_LIB", "")
+LIB_PATH = os.path.join(_HERE, "lib", "libsttm_hip_dev.so" if _which == "dev" else (_which if _which.endswith(".so") else "libsttm_hip.so"))
 
 STTM_F32, STTM_BF16, STTM_F16 = 0, 1, 2
 ERR_ARG, ERR_UNSUPPORTED, ERR_LAUNCH, ERR_INDEX, ERR_PARITY, ERR_TIMEOUT = -1, -2, -3, -4, -5, -6

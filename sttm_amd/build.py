@@ -64,7 +64,12 @@ def build(force=False, verbose=False, extra_flags=(), dev=False):
     lib = os.path.join(LIBDIR, "libsttm_hip_dev.so") if dev else LIB
     if dev:
         extra_flags = tuple(extra_flags) + ("-DSTTM_DEV",)
-    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    common = [os.path.join(CSRC, h) for h in HEADERS if not h.endswith(".inc")]
+    # the two big template files are included by some translation units only
+    inc_users = {"quadtree_spatial.inc": lambda src: src.startswith("spatial_"), "sttm_pairs.inc": lambda src: src == "temporal_merge.hip"}
+
+    def deps(src):
+        return common + [os.path.join(CSRC, inc) for inc, uses in inc_users.items() if uses(src)]
     tag = source_tag(extra_flags) + ("-dev" if dev else "")
     tag_file = os.path.join(objdir, ".build_tag")
     old = open(tag_file).read().split() if os.path.exists(tag_file) else []
@@ -79,7 +84,7 @@ def build(force=False, verbose=False, extra_flags=(), dev=False):
         extra = [f'-DSTTM_BUILD_TAG="{tag}"'] if src == "api.hip" else []
         # changed FLAGS rebuild every object (they apply to all of them); a changed source rebuilds the objects older than it, plus
         # api.o, which has the source + flags tag baked in (sttm_build_tag)
-        if force or flags_changed or _stale(o, [s] + hdrs) or (src == "api.hip" and old_tag != tag):
+        if force or flags_changed or _stale(o, [s] + deps(src)) or (src == "api.hip" and old_tag != tag):
             jobs.append([_hipcc(), *FLAGS, *extra_flags, *extra, "-c", s, "-o", o])
     def run(cmd):
         if verbose:
