@@ -190,7 +190,8 @@ int sttm_quadtree_merge_batch(int n_videos, const void* const* x, int64_t stride
  *                 stand-alone label kernel; the folded form is no faster on MI355X and is kept for experiments)
  *   "pairs_var"   9: the general pair kernel instead of the lean 256-thread form (tests / A-B)
  *   "k1_var"      development build only (A/B): 1 = 3-level trees run the general spatial body (the one deeper trees use)
- *   "no_dense"    1: column label stage always on compact ids (default: columns of <= 4096 slots work on their slots directly)
+ *   "no_dense"    1: column label stage always on compact ids (default: columns of <= 4096 slots work on their slots directly);
+ *                 2: the round-3 form of the slot-indexed stage (three barriers per iteration; A/B)
  *   "no_fuse"     1: stand-alone label stage as two launches (no in-kernel grid barrier)
  *   "force_gmem_labels"  1: label stage on global scratch instead of LDS (the path of columns too large for LDS)
  *   "tome_split"  ToMe match kernel for float32 inputs.  1 (default): unit rows as two fp16 planes (h + l of 4096 v, residual
@@ -202,6 +203,8 @@ int sttm_quadtree_merge_batch(int n_videos, const void* const* x, int64_t stride
  *   "tome_flat"   256-tile ToMe match kernels: 1 (default) spread all tile products evenly over one workgroup per CU when that
  *                 shortens the per-CU critical path against the best per-a-tile split (69 x 69 tiles at T = 180: 19 instead of 23
  *                 products per workgroup), 0 never, 2 always.  Same scores, same first-maximum argmax.
+ *   "tome_rank"   ToMe ranking of the a-tokens: 0 (default) by counting in one kernel for clips of up to 49 152 a-tokens, 1 always the
+ *                 radix sort path (A/B, tests).  Same order: descending best score, ties to the smaller token index.
  */
 int sttm_configure(const char* key, int value);
 

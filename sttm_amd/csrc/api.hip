@@ -24,7 +24,7 @@ int fail(int code, const char* fmt, ...) {
 // Tuning / test switches: defaults from STTM_<KEY> environment variables, read ONCE; sttm_configure overrides them.
 // None of them changes results.
 struct Config {
-    int pairs_seg, pairs_nt, pairs_var, k1_var, no_dense, gm_split, label_nt, vec16, vec32, fold_kb, fold_labels, no_fuse, force_gmem_labels, tome_split, tome_flat;
+    int pairs_seg, pairs_nt, pairs_var, k1_var, no_dense, gm_split, label_nt, vec16, vec32, fold_kb, fold_labels, no_fuse, force_gmem_labels, tome_split, tome_flat, tome_rank;
 };
 int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
@@ -48,6 +48,7 @@ Config& config() {
         d.force_gmem_labels = env_int("STTM_FORCE_GMEM_LABELS", 0);
         d.tome_split = env_int("STTM_TOME_SPLIT", 1);
         d.tome_flat = env_int("STTM_TOME_FLAT", 1);
+        d.tome_rank = env_int("STTM_TOME_RANK", 0);
         return d;
     }();
     return c;
@@ -410,7 +411,7 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
     ta.max_slots = p.max_slots;
     ta.force_gmem = cfg.force_gmem_labels ? 1 : 0;
     ta.no_fuse = (cfg.no_fuse || (flags & STTM_FLAG_NO_FUSE)) ? 1 : 0;
-    ta.no_dense = cfg.no_dense ? 1 : 0;
+    ta.no_dense = cfg.no_dense;          // 0: dense form (round 4), 1: compact ids, 2: round 3's dense form (A/B)
     ta.want_fold = cfg.fold_labels ? 1 : 0;
     ta.fold_kb = cfg.fold_kb > 0 ? cfg.fold_kb : 64;
     ta.S = b.S; ta.xrows = dense ? x[0] : nullptr; ta.meta = b.meta; ta.inrm = b.inrm; ta.rc_list = b.rc_list; ta.rc_stride = p.rc_stride;
@@ -476,6 +477,7 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
 namespace sttm {
 int tome_split_mode() { return config().tome_split; }
 int tome_flat_mode() { return config().tome_flat; }
+int tome_rank_mode() { return config().tome_rank; }
 }  // namespace sttm
 
 extern "C" {
@@ -492,7 +494,7 @@ int sttm_configure(const char* key, int value) {
     Config& c = config();
     struct { const char* name; int* slot; } keys[] = {
         {"pairs_seg", &c.pairs_seg}, {"pairs_nt", &c.pairs_nt}, {"pairs_var", &c.pairs_var}, {"k1_var", &c.k1_var}, {"no_dense", &c.no_dense}, {"gm_split", &c.gm_split}, {"label_nt", &c.label_nt},
-        {"vec16", &c.vec16}, {"vec32", &c.vec32}, {"fold_kb", &c.fold_kb}, {"fold_labels", &c.fold_labels}, {"no_fuse", &c.no_fuse}, {"tome_split", &c.tome_split}, {"tome_flat", &c.tome_flat},
+        {"vec16", &c.vec16}, {"vec32", &c.vec32}, {"fold_kb", &c.fold_kb}, {"fold_labels", &c.fold_labels}, {"no_fuse", &c.no_fuse}, {"tome_split", &c.tome_split}, {"tome_flat", &c.tome_flat}, {"tome_rank", &c.tome_rank},
         {"force_gmem_labels", &c.force_gmem_labels},
     };
     for (auto& k : keys)

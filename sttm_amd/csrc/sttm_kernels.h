@@ -111,7 +111,7 @@ struct TemporalArgs {
     int32_t* col_arrive;      // [R] arrivals of a column's pair workgroups (zeroed by the spatial kernel)
     int32_t* frame_cnt;       // [T] survivors per frame (zeroed by the spatial kernel)
     int32_t* bar;             // [8] overflow flag, N' word, grid-barrier word (zeroed by the spatial kernel)
-    int no_dense;             // option: never use the uncompacted (slot-indexed) form of the column label stage
+    int no_dense;             // option: 1 = never use the uncompacted (slot-indexed) form of the column label stage, 2 = its round-3 form
     int no_fuse, want_fold;   // options: two-launch label path / label stage inside the pair kernel (opt-in)
     int fold_kb;              // LDS budget (KB) of a pair workgroup when the label stage is folded in
     int fold_labels;          // the last pair workgroup of a column to arrive runs that column's label stage
@@ -159,6 +159,7 @@ size_t colscratch_ints(int T, int H, int W, int R);
 void pairs_shape(int T, int R, int fold, int want_seg, int want_nt, int* seg, int* nt);
 
 int tome_flat_mode();        // 256-tile ToMe match kernels: 1 = tile products spread evenly over the CUs when that is shorter, 0 = never, 2 = always
+int tome_rank_mode();        // 0 = ranking by counting (clips of up to 49 152 a-tokens), 1 = always the radix sort path (A/B, tests)
 int tome_split_mode();       // 0 = fp32-input MFMA match kernel; > 0 = fp16 two-plane split variants (api.hip: Config)
 
 hipError_t launch_pool2d(const void* x, void* out, int T, int H, int W, int C, int OH, int OW, int stride, int mode, int dtype,

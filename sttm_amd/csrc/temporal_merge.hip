@@ -182,6 +182,11 @@ struct ColShared {   // small per-workgroup scratch, carved from dynamic LDS
     int last;        // k_pairs: this workgroup is the column's last arriver
     int ok;          // grid barrier passed
     int kfast;       // K as read off the barrier word (0: not decided there)
+    // dense form (round 4): one flag per iteration (never reset: no barrier between reading a flag and the next iteration), the
+    // totals of the closing reduction and the count of waves that have added theirs
+    int ch[64], bd[64];
+    int tot[4];
+    int arrived;
 };
 
 template <bool GMEM> __device__ __forceinline__ void edge_get(const int* edges, int e, int& d, int& s) {
@@ -566,6 +571,274 @@ __device__ __forceinline__ bool column_labels(const TemporalArgs& a, int r, cons
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The DENSE form of the column label stage, rebuilt around its barriers (round 4).  Same arithmetic as column_labels<false, MODE,
+// true> (ids = the column's slots, LDS only); what changed is the number of workgroup barriers between dependent steps -- at
+// 1024 threads every one of them is ~0.2 us of a 16-workgroup kernel that is nothing but dependent steps:
+//   * the first round of edge-list loads is requested BEFORE the LDS tables are initialised (the init runs under the round trip);
+//     labels and scatter target are initialised in that same phase (the old form spent a pass + a barrier on it after the gather);
+//   * an iteration is TWO barriers instead of three: the idempotency check of iteration k (read-only on the labels) rides in the
+//     edge pass of iteration k + 1, and the copy pass is gone -- the pointer-jump pass writes the next scatter target itself
+//     (three arrays: labels, scatter target, next scatter target; the compact-id table of the other form is free here).  The
+//     iteration that finds nothing changed needs no check (a stable labelling is idempotent);
+//   * the group-size table is cleared before the grid barrier (whose own barriers order it) instead of behind it;
+//   * the closing reduction has no barrier: every wave adds its partial sums to LDS totals and the LAST wave to arrive publishes.
+// Returns false (no global side effects yet) when the column has more kept edges than `arr.cap`.
+// ---------------------------------------------------------------------------------------------------
+template <int MODE>
+__device__ __forceinline__ bool column_labels_dense(const TemporalArgs& a, int r, const Column& col, const ColArrays& arr, ColShared* sh) {
+    const int R = a.R;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int lane = tid & 63, nwave = nt >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slots = col.slots, W = (slots + 31) >> 5;
+    const bool temporal = a.temporal_thresh > 0.f && a.T > 1;
+    int* L = arr.rep; int* Sa = arr.rep2; int* Sb = arr.cslot; int* edges = arr.edges;
+    int* bits = arr.bits; int* dec = arr.dec;
+    const int nf = a.T - 1;
+    int E = 0, K = 0, cand_pre = 0, ovf = 0;
+    STTM_LBL_TICK(0);
+    // ---- loads first: list heads (consumed at the very end), candidate counts, overflow flag, the first round of edge lists ----
+    const unsigned head_pre = tid < a.T ? (unsigned)a.rc_list[(int64_t)(tid * R + r) * a.rc_stride] : 0u;
+    if (temporal)
+        for (int t = tid; t < nf; t += nt) cand_pre += ld_agent(a.cand_cnt + (int64_t)r * nf + t);
+    if (tid == 0) ovf = ld_agent(a.bar + 1);
+    constexpr int HEAD = 16, PER = 2;           // a list holds two edges on average; one longer than HEAD is walked with dependent loads (rare)
+    const int cap = a.ecap;
+    const int32_t* elist = a.edges + (int64_t)r * nf * cap;
+    const int32_t* ecnt = a.edge_cnt + (int64_t)r * nf;
+    const int total = temporal ? nf * HEAD : 0;
+    int val[PER], tt[PER], cn[PER];
+    auto fetch = [&](int j0) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int j = j0 + k * nt + tid;
+            const bool in = j < total;
+            const int t = j / HEAD, e = j % HEAD;
+            val[k] = (in && e < cap) ? ld_agent(elist + (int64_t)t * cap + e) : 0;
+            cn[k] = in ? ld_agent(ecnt + t) : 0;
+            tt[k] = t;
+        }
+    };
+    fetch(0);
+    // ---- LDS tables (under the round trip) ----------------------------------------------------------------------------------
+    for (int t = tid; t < a.T; t += nt) dec[t] = 0;
+    for (int w = tid; w < W; w += nt) bits[w] = 0;
+    for (int s2 = tid; s2 < slots; s2 += nt) { L[s2] = s2; Sa[s2] = s2; }
+    if (tid < 64) { sh->ch[tid] = 0; sh->bd[tid] = 0; }
+    if (tid < 4) sh->tot[tid] = 0;
+    if (tid == 0) { sh->ecount = 0; sh->arrived = 0; }
+    lds_barrier();
+    if (temporal) {
+        auto take = [&](int t, int packed, int pos) {
+            const unsigned w = (unsigned)packed;
+            const int sd = t * col.A + (int)(w >> 16), ss = (t + 1) * col.A + (int)(w & 0xffffu);
+            if (pos < arr.cap) edge_put<false>(edges, pos, sd, ss);
+            atomicOr(bits + (sd >> 5), (int)(1u << (sd & 31)));
+            atomicOr(bits + (ss >> 5), (int)(1u << (ss & 31)));
+        };
+        for (int j0 = 0; j0 < total; j0 += PER * nt) {
+            if (j0 > 0) fetch(j0);
+            bool ok[PER];
+            int nv = 0;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int j = j0 + k * nt + tid;
+                ok[k] = j < total && (j % HEAD) < cn[k];
+                nv += ok[k] ? 1 : 0;
+            }
+            // compaction with ONE LDS atomic per wave and round (a same-address atomic per kept edge serialises)
+            int incl = nv;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int v = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += v;
+            }
+            int base = 0;
+            if (lane == 63 && incl) base = atomicAdd(&sh->ecount, incl);
+            base = __shfl(base, 63, 64);
+            int pos = base + incl - nv;
+#pragma unroll
+            for (int k = 0; k < PER; ++k)
+                if (ok[k]) take(tt[k], val[k], pos++);
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int j = j0 + k * nt + tid;
+                if (j < total && j % HEAD == 0 && cn[k] > HEAD)
+                    for (int e = HEAD; e < cn[k] && e < cap; ++e)
+                        take(tt[k], ld_agent(elist + (int64_t)tt[k] * cap + e), atomicAdd(&sh->ecount, 1));
+            }
+        }
+        lds_barrier();
+        E = sh->ecount;
+        if (E > arr.cap) return false;
+    }
+    STTM_LBL_TICK(1);
+    STTM_LBL_TICK(2);
+    // one synchronous iteration in the old (three-barrier) form: replays only
+    auto replay = [&](int k_iters) {
+        for (int i = tid; i < slots; i += nt) { L[i] = i; Sa[i] = i; }
+        lds_barrier();
+        for (int it2 = 0; it2 < k_iters; ++it2) column_iteration<false>(L, Sa, edges, E, slots, sh->flags);
+    };
+    int probe_iters = 0;
+    unsigned long long history = ~0ull;          // a column without edges never moves
+    int* gs = Sb;                                // group sizes go to whichever scatter array is stale at the end
+    if (MODE != COL_FINAL && temporal && E > 0) {
+        // ---- PROBE: to the fixed point, two barriers per iteration --------------------------------------------------------------
+        unsigned long long mask = 0ull;
+        int it = 0;
+        bool overflow = false;
+        int* Sc = Sa; int* Sn = Sb;              // scatter target of this iteration (== labels on entry) | of the next one
+        while (true) {
+            for (int e = tid; e < E; e += nt) {
+                int d, s2;
+                edge_get<false>(edges, e, d, s2);
+                const int rd = L[d], rs = L[s2];
+                const int m = rd < rs ? rd : rs;
+                atomicMin(Sc + d, m);
+                atomicMin(Sc + s2, m);
+            }
+            if (it > 0) {                        // idempotency of the labels iteration it - 1 left (read-only: rides along)
+                int bad = 0;
+                for (int i = tid; i < slots; i += nt) {
+                    const int v = L[i];
+                    if (L[v] != v) bad = 1;
+                }
+                if (bad) sh->bd[it - 1] = 1;
+            }
+            lds_barrier();
+            int changed = 0;
+            for (int i = tid; i < slots; i += nt) {
+                const int v = Sc[Sc[i]];
+                if (v != L[i]) changed = 1;
+                L[i] = v;
+                Sn[i] = v;
+            }
+            if (changed) sh->ch[it] = 1;
+            lds_barrier();
+            if (it > 0 && !sh->bd[it - 1]) mask |= 1ull << (it - 1);
+            const int chg = sh->ch[it];
+            ++it;
+            int* tmp = Sc; Sc = Sn; Sn = tmp;
+            if (!chg) break;                     // fixed point: stable => idempotent from here on
+            if (it >= kMaxProbeIters) { overflow = true; break; }
+        }
+        mask |= ~0ull << (it - 1);               // the last iteration changed nothing: it and every later one are idempotent ...
+        // (iteration it - 2's own check rode in iteration it - 1's edge pass)
+        history = mask;
+        if (tid == 0) {
+            __hip_atomic_store(a.col_mask + r, mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (overflow) ovf += 1;
+        }
+        probe_iters = it;
+        gs = Sn;                                 // stale; Sc is a copy of the labels
+    } else if (MODE != COL_FINAL && temporal && tid == 0) {
+        __hip_atomic_store(a.col_mask + r, history, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        probe_iters = 1;
+    }
+    if (MODE != COL_FINAL && temporal && E == 0) probe_iters = 1;
+    if constexpr (MODE == COL_PROBE) return true;
+    STTM_LBL_TICK(3);
+    for (int i = tid; i < slots; i += nt) gs[i] = 0;            // ordered by the barriers below
+    bool alive = true;
+    if constexpr (MODE == COL_FUSED) {
+        alive = grid_barrier(reinterpret_cast<unsigned long long*>(a.bar + 4), R, history, &sh->ok, &sh->kfast);
+        if (!alive) {
+            ovf += 1;
+            if (tid == 0) __hip_atomic_fetch_or(a.bar + 1, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else {
+        lds_barrier();
+    }
+    STTM_LBL_TICK(4);
+    int nodes = 0, leafnodes = 0, survivors = 0;
+    if (alive) {
+        if (temporal) {
+            const int kfast = MODE == COL_FUSED ? sh->kfast : 0;
+            if (kfast > 0) {
+                K = kfast;
+            } else {
+                unsigned long long m = ~0ull;
+                for (int c = tid; c < R; c += nt) m &= __hip_atomic_load(a.col_mask + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) m &= __shfl_xor(m, d, 64);
+                if (lane == 0) sh->wmask[wave] = m;
+                lds_barrier();
+                unsigned long long all = ~0ull;
+                for (int w = 0; w < nwave; ++w) all &= sh->wmask[w];
+                K = all ? __ffsll((long long)all) : kMaxProbeIters;
+            }
+            if (E > 0 && (MODE == COL_FINAL || K < probe_iters - 1)) {
+                replay(K);                                   // ends with a barrier; both scatter arrays of the probe are dead now
+                gs = Sb;
+                for (int i = tid; i < slots; i += nt) gs[i] = 0;
+                lds_barrier();
+            }
+            STTM_LBL_TICK(5);
+            if (E > 0) {
+                for (int i = tid; i < slots; i += nt) atomicAdd(gs + L[i], 1);
+                lds_barrier();
+                for (int i = tid; i < slots; i += nt) {
+                    if (!(((unsigned)bits[i >> 5] >> (i & 31)) & 1u)) continue;       // no node with a kept edge starts at this slot
+                    const int rr = L[i];
+                    const int row = slot_to_row(a, col, i);
+                    if (rr == i) {
+                        a.gcnt[row] = gs[i];
+                    } else {
+                        a.lab_row[row] = slot_to_row(a, col, rr);
+                        a.gcnt[row] = 0;
+                        atomicAdd(dec + slot_frame(col, i), 1);
+                    }
+                }
+                lds_barrier();
+            }
+            STTM_LBL_TICK(6);
+        }
+        for (int t = tid; t < a.T; t += nt) {
+            const unsigned head = t == tid ? head_pre : (unsigned)a.rc_list[(int64_t)(t * R + r) * a.rc_stride];
+            const int n_t = (int)(head & 0xffffu), c = n_t - dec[t];
+            nodes += n_t; leafnodes += (int)(head >> 16); survivors += c;
+            if (c) atomicAdd(a.frame_cnt + t, c);
+        }
+        STTM_LBL_TICK(7);
+    }
+    // ---- N' and the bookkeeping counters, without a barrier: the last wave to add its partial sums publishes --------------------
+    int cand = temporal ? cand_pre : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        nodes += __shfl_xor(nodes, d, 64); leafnodes += __shfl_xor(leafnodes, d, 64);
+        survivors += __shfl_xor(survivors, d, 64); cand += __shfl_xor(cand, d, 64);
+    }
+    if (lane == 0) {
+        if (nodes) atomicAdd(&sh->tot[0], nodes);
+        if (leafnodes) atomicAdd(&sh->tot[1], leafnodes);
+        if (survivors) atomicAdd(&sh->tot[2], survivors);
+        if (cand) atomicAdd(&sh->tot[3], cand);
+        atomicAdd(&sh->arrived, 1);                              // (the LDS operations of a wave are performed in order)
+    }
+    if (tid == 0) {                                              // thread 0 carries the overflow events: it publishes
+        while (atomicAdd(&sh->arrived, 0) < nwave) __builtin_amdgcn_s_sleep(1);       // LDS only; the other waves are a few instructions away
+        const int t0 = atomicAdd(&sh->tot[0], 0), t1 = atomicAdd(&sh->tot[1], 0), t2 = atomicAdd(&sh->tot[2], 0), t3 = atomicAdd(&sh->tot[3], 0);
+        unsigned long long* word = reinterpret_cast<unsigned long long*>(a.bar + 2);
+        const unsigned long long mine = ((unsigned long long)(ovf > 127 ? 127 : ovf) << 56) | ((unsigned long long)(unsigned)t2 << 24) | 1ull;
+        (void)__hip_atomic_fetch_add(word, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.early_host) {
+            const bool timed_out = MODE == COL_FUSED && !alive;
+            const unsigned long long w = ((unsigned long long)(unsigned)a.seq << 32) | (timed_out ? 0x80000000ull : 0ull) |
+                                         ((ovf && !timed_out) ? 0x40000000ull : 0ull) | (unsigned long long)((unsigned)t2 & 0x0fffffffu);
+            __hip_atomic_store(a.early_host + r, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (t0) atomicAdd(a.counts + STTM_CNT_NODES, t0);
+        if (t1) atomicAdd(a.counts + STTM_CNT_LEAFNODES, t1);
+        if (t3) atomicAdd(a.counts + STTM_CNT_CANDIDATES, t3);
+        if (E) atomicAdd(a.counts + STTM_CNT_EDGES, E);
+        if (r == 0) st_agent(a.counts + STTM_CNT_ITERS, K);
+    }
+    STTM_LBL_TICK(8);
+    return true;
+}
+
 // LDS bytes of a column working set with room for `cap` active nodes / edges
 __host__ __device__ inline size_t col_lds_bytes(int cap, int slots, int T) {
     const size_t W = ((size_t)slots + 31) / 32;
@@ -604,9 +877,10 @@ __device__ __forceinline__ void column_labels_any(const TemporalArgs& a, const L
     ColShared* sh;
     const ColArrays lds = col_arrays_lds(smem, cap > 0 ? cap : 0, cap > 0 ? col.slots : 0, cap > 0 ? a.T : 0, &sh);
     if (cap > 0 && !a.force_gmem) {
-        if (col.slots <= kDenseSlots && col.slots <= cap && !a.no_dense) {
-            if (column_labels<false, MODE, true>(a, r, col, lds, sh)) return;       // (false: more kept edges than room -- cannot happen
-            __syncthreads();                                                       //  while cap >= slots; the compact form decides)
+        if (col.slots <= kDenseSlots && col.slots <= cap && a.no_dense != 1) {
+            // (false: more kept edges than room -- cannot happen while cap >= slots; the compact form decides)
+            if (a.no_dense == 2 ? column_labels<false, MODE, true>(a, r, col, lds, sh) : column_labels_dense<MODE>(a, r, col, lds, sh)) return;
+            __syncthreads();
         }
         if (column_labels<false, MODE>(a, r, col, lds, sh)) return;
         __syncthreads();
@@ -1145,8 +1419,12 @@ __global__ void __launch_bounds__(256, OCC) k_group_mean(const TemporalArgs a0, 
             return r;
         };
         int jk = j0 + ((me - j0) & (stride - 1));              // first rank >= j0 congruent to me (stride is a power of two)
-        for (; jk < j0 + nchunk; jk += stride) {
-            GmRow r = find(jk);
+        // one survivor: everything from its metadata to its stores.  `acc` arrives loaded with the row's first pass when PRE.
+        auto row_desc = [&](const void* basep, int row, int cb) {
+            const char* q = reinterpret_cast<const char*>(basep) + ((int64_t)row * a.C + cb) * eb;
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(q), 0, (a.C - cb) * eb, 0x00020000);
+        };
+        auto finish = [&](GmRow r, Pack<T, VEC> (&acc)[U], bool pre) {
 #ifdef STTM_DEV
             if (a.dev.k5_mode == 1) r.n = 1;
 #endif
@@ -1157,16 +1435,13 @@ __global__ void __launch_bounds__(256, OCC) k_group_mean(const TemporalArgs a0, 
             const int origin = t * HW + r.p;
             int patches = area;
             const void* s0 = (area == 1 && a.xrows) ? a.xrows : a.S;      // 1x1 nodes were not copied out of x
-            auto rdesc = [&](const void* basep, int row, int cb) {
-                const char* q = reinterpret_cast<const char*>(basep) + ((int64_t)row * a.C + cb) * eb;
-                return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(q), 0, (a.C - cb) * eb, 0x00020000);
-            };
             for (int cb0 = 0; cb0 < a.C; cb0 += CH) {
-                Pack<T, VEC> acc[U];
                 // ---- everything this pass needs first: the row's chunks and, for a group survivor, the 64 slots behind it
-                const __amdgpu_buffer_rsrc_t d = rdesc(s0, origin, cb0);
+                if (!(pre && cb0 == 0)) {
+                    const __amdgpu_buffer_rsrc_t d = row_desc(s0, origin, cb0);
 #pragma unroll
-                for (int u = 0; u < U; ++u) acc[u] = load_pack_buf<T, VEC>(d, (uint32_t)((u * 64 + lane) * VEC * eb));
+                    for (int u = 0; u < U; ++u) acc[u] = load_pack_buf<T, VEC>(d, (uint32_t)((u * 64 + lane) * VEC * eb));
+                }
                 if (n > 1) {
                     const Column col = column_from_geo(a, r.geo);
                     const int slot0 = t * col.A + (y1 - col.Y1) * col.aw + (x1 - col.X1);
@@ -1192,7 +1467,7 @@ __global__ void __launch_bounds__(256, OCC) k_group_mean(const TemporalArgs a0, 
                             mm &= mm - 1ull;
                             const int mr = __builtin_amdgcn_readlane(mrow, k), ak = __builtin_amdgcn_readlane(ar, k);
                             const void* sm = (ak == 1 && a.xrows) ? a.xrows : a.S;
-                            const __amdgpu_buffer_rsrc_t dm = rdesc(sm, mr, cb0);
+                            const __amdgpu_buffer_rsrc_t dm = row_desc(sm, mr, cb0);
                             Pack<T, VEC> qv[U];
 #pragma unroll
                             for (int u = 0; u < U; ++u) qv[u] = load_pack_buf<T, VEC>(dm, (uint32_t)((u * 64 + lane) * VEC * eb));
@@ -1214,7 +1489,7 @@ __global__ void __launch_bounds__(256, OCC) k_group_mean(const TemporalArgs a0, 
                         pack_fill(acc[u], [&](int e) { return prev.get(e) / den; });
                     }
                 }
-                const __amdgpu_buffer_rsrc_t dout = rdesc(a.feat_out, r.out, cb0);
+                const __amdgpu_buffer_rsrc_t dout = row_desc(a.feat_out, r.out, cb0);
 #pragma unroll
                 for (int u = 0; u < U; ++u) store_pack_buf<T, VEC>(dout, (uint32_t)((u * 64 + lane) * VEC * eb), acc[u]);
             }
@@ -1223,6 +1498,13 @@ __global__ void __launch_bounds__(256, OCC) k_group_mean(const TemporalArgs a0, 
                 int32_t* o = a.tlbr_out + (int64_t)r.out * 5;
                 o[0] = t; o[1] = y1; o[2] = x1; o[3] = y2; o[4] = x2;
             }
+        };
+        // (two survivors per wave and step with both rows in flight and a quarter of the waves -- all resident at once, a frame's
+        // metadata fetched by fewer waves -- was built in round 4 and measured slower in every configuration: headline 23.4 -> 24.8 us,
+        // bf16 C=3584 40.4 -> 44.5 us; one row per wave and as many waves as possible stays)
+        for (; jk < j0 + nchunk; jk += stride) {
+            Pack<T, VEC> acc[U];
+            finish(find(jk), acc, false);
         }
         j0 += nchunk;
     }

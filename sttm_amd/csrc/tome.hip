@@ -810,6 +810,121 @@ __global__ void k_tome_fill(const int* __restrict__ order, const int* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Ranking by counting (round 4): replaces k_tome_unpack + hipcub::DeviceRadixSort (4 launches) + k_tome_count for clips of up to
+// kRankMax a-tokens.  argsort(node_max, descending) with ties to the smaller index (tome_token_merger.py:37; the stable order the
+// radix sort produced):  rank_i = #{ j : key_j > key_i }  on the 64-bit keys  (order-preserving bits of the score << 32) | ~i,
+// which are all distinct.  12 544 a-tokens (T = 128) are 1.6e8 compares -- microseconds of VALU time -- against ~45 us of
+// launches and passes for the sort and its bookkeeping.  Workgroup (ib, js): 256 a-tokens (one per thread) against the js-th part
+// of the keys, staged through LDS in tiles and read back as broadcasts; partial counts meet in `rank` (zeroed) through atomics,
+// and the LAST part of an a-block to arrive (per-block arrival counter) turns the complete ranks into `order`, writes the
+// unpacked node_max / node_idx and counts the sources of every destination (rank < r) -- the old k_tome_count; the a-block that
+// completes last of all scans those counts (the old k_tome_scan).
+// ---------------------------------------------------------------------------------------------------
+constexpr int kRankMax = 49152;        // beyond that (T > ~500 frames of 196 tokens) the radix sort path is used
+constexpr int RK_I = 256;
+constexpr int kRankParts = 32;         // most key-range parts per a-block (partial ranks are [parts][na] ints of workspace)
+
+__device__ __forceinline__ unsigned long long tome_rank_key(unsigned long long b, int i) {
+    const unsigned ku = b ? (unsigned)(b >> 32) : 0xffc00000u;          // no finite score at all: a NaN row (sorts first, like the radix sort)
+    return ((unsigned long long)ku << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
+}
+
+__global__ void __launch_bounds__(RK_I) k_tome_rank(const unsigned long long* __restrict__ best, int na, int jsplit, int r,
+                                                    int* __restrict__ rank, int* __restrict__ arrive, float* __restrict__ node_max,
+                                                    int* __restrict__ node_idx, int* __restrict__ order, int* __restrict__ cnt,
+                                                    int nb, int* __restrict__ off) {
+    __shared__ __attribute__((aligned(16))) unsigned tile[RK_I];
+    __shared__ int last_sh, all_sh;
+    __shared__ int wsum[RK_I / 64];
+    const int ib = blockIdx.x / jsplit, js = blockIdx.x - ib * jsplit;
+    const int tid = threadIdx.x;
+    const int i = ib * RK_I + tid;
+    const unsigned long long bi = i < na ? best[i] : 0ull;
+    const unsigned long long ki = tome_rank_key(bi, i);
+    const int chunk = ((na + jsplit - 1) / jsplit + RK_I - 1) / RK_I * RK_I;
+    const int jlo = js * chunk, jhi = min(na, jlo + chunk);
+    // Keys are compared as 32-bit score bits; the index tie-break (j < i) is UNIFORM for every 256-key block other than the
+    // workgroup's own one (blocks are aligned): blocks before it count `>=`, blocks after it `>`, one compare + one add per key;
+    // only the diagonal block takes the three-compare form.  Keys are staged in LDS as 32-bit words and read back four per
+    // broadcast.  (First version: 64-bit keys and compares, one LDS broadcast per key: 67 us for 12.5 k keys; j-side in scalar
+    // registers through the scalar cache: 127 us.)
+    const unsigned kui = (unsigned)(ki >> 32);
+    int c = 0;
+    for (int j0 = jlo; j0 < jhi; j0 += RK_I) {       // one aligned block of 256 keys per step
+        const int jj = j0 + tid;
+        tile[tid] = jj < jhi ? (unsigned)(tome_rank_key(best[jj], jj) >> 32) : 0u;      // 0 is below every key
+        __syncthreads();
+        const int nq = min(RK_I, jhi - j0);
+        if (j0 == ib * RK_I) {                       // the diagonal block
+            for (int q = 0; q < nq; ++q) {
+                const unsigned kj = tile[q];
+                c += (kj > kui || (kj == kui && j0 + q < i)) ? 1 : 0;
+            }
+        } else if (j0 < ib * RK_I) {                 // every j of the block is before every i of the workgroup
+#pragma unroll 8
+            for (int q = 0; q < RK_I; q += 4) {
+                const uint4 k4 = *reinterpret_cast<const uint4*>(tile + q);
+                c += (k4.x >= kui) + (k4.y >= kui) + (k4.z >= kui) + (k4.w >= kui);
+            }
+        } else {
+#pragma unroll 8
+            for (int q = 0; q < RK_I; q += 4) {
+                const uint4 k4 = *reinterpret_cast<const uint4*>(tile + q);
+                c += (k4.x > kui) + (k4.y > kui) + (k4.z > kui) + (k4.w > kui);
+            }
+        }
+        __syncthreads();
+    }
+    // Everything that crosses workgroups here is an agent-scope atomic (performed at the device's coherence point) read back with
+    // agent-scope loads: every wave drains its own (vmcnt), then ONE relaxed arrival -- no release / acquire fences, which on this
+    // multi-XCD part are L2 write-backs + invalidates per workgroup (a __threadfence() here made the kernel 67 - 120 us).
+    // (partial counts as plain coalesced write-through stores into rank[js][i], summed by the last part to arrive: as atomics on
+    // rank[i] they were 25 memory-side read-modify-writes per a-token, most of the kernel's 33 us)
+    if (i < na) __hip_atomic_store(rank + (size_t)js * na + i, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) last_sh = __hip_atomic_fetch_add(arrive + ib, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == jsplit - 1;
+    __syncthreads();
+    if (!last_sh) return;
+    if (i < na) {
+        int rk = 0;
+        for (int q = 0; q < jsplit; ++q) rk += __hip_atomic_load(rank + (size_t)q * na + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        order[rk] = i;
+        unsigned u = (unsigned)(bi >> 32);
+        u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+        const int dst = bi ? (int)(0xffffffffu - (unsigned)(bi & 0xffffffffu)) : 0;
+        node_max[i] = bi ? __uint_as_float(u) : __uint_as_float(0x7fc00000u);
+        node_idx[i] = dst;
+        if (rk < r) atomicAdd(cnt + dst, 1);
+    }
+    // the a-block that completes LAST of all (slot `iblocks` of the arrival counters) scans the per-destination counts: the old
+    // one-workgroup k_tome_scan, without a launch of its own
+    const int iblocks = (na + RK_I - 1) / RK_I;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) all_sh = __hip_atomic_fetch_add(arrive + iblocks, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == iblocks - 1;
+    __syncthreads();
+    if (!all_sh) return;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int per = (nb + RK_I - 1) / RK_I;
+    const int lo = min(tid * per, nb), hi = min(lo + per, nb);
+    int total = 0;
+    for (int q = lo; q < hi; ++q) total += __hip_atomic_load(cnt + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int inc = total;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int pre = inc - total;
+    for (int w = 0; w < wave; ++w) pre += wsum[w];
+    for (int q = lo; q < hi; ++q) { off[q] = pre; pre += __hip_atomic_load(cnt + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    if (tid == RK_I - 1) off[nb] = pre;
+}
+
 // one wave per output row.  rows [0, na - r): unmerged a-tokens in rank order; rows [na - r, n - r): b-tokens.
 // Every tensor of the reference is rounded to the input dtype T (x * size, the scatter-added sums, the sums of sizes, the
 // quotient): for T = float that is the plain fp32 arithmetic of the reference, without contraction.
@@ -916,7 +1031,7 @@ __global__ void __launch_bounds__(256) k_tome_merge(const void* __restrict__ x, 
 
 struct TomePlan {
     int na, nb, D, Dp;
-    size_t off_ahat, off_bhat, off_best, off_nmax, off_nidx, off_iota, off_keys, off_order, off_cnt, off_cur, off_off,
+    size_t off_ahat, off_bhat, off_best, off_nmax, off_nidx, off_iota, off_keys, off_order, off_cnt, off_cur, off_rank, off_arrive, off_off, off_parts,
         off_lists, off_cub, cub_bytes, total;
 };
 
@@ -940,16 +1055,21 @@ static int tome_plan(int n, int C, int n_head, TomePlan* p) {
     size_t o = 0;
     p->off_ahat = o; o = al(o + (size_t)p->na * p->Dp * 4);
     p->off_bhat = o; o = al(o + (size_t)(p->nb > 0 ? p->nb : 1) * p->Dp * 4);
-    p->off_best = o; o = al(o + (size_t)p->na * 8);
     p->off_nmax = o; o = al(o + (size_t)p->na * 4);
     p->off_nidx = o; o = al(o + (size_t)p->na * 4);
     p->off_iota = o; o = al(o + (size_t)p->na * 4);
     p->off_keys = o; o = al(o + (size_t)p->na * 4);
     p->off_order = o; o = al(o + (size_t)p->na * 4);
+    // ONE zeroed region [off_best, off_off): the packed best scores, the per-destination counts and cursors, the partial ranks and
+    // the per-block arrival counters of the ranking kernel
+    p->off_best = o; o = al(o + (size_t)p->na * 8);
     p->off_cnt = o; o = al(o + (size_t)(p->nb + 1) * 4);
     p->off_cur = o; o = al(o + (size_t)(p->nb + 1) * 4);
+    p->off_rank = o; o = al(o + (size_t)p->na * 4);               // (not part of the zeroed region any more: see off_parts)
+    p->off_arrive = o; o = al(o + (size_t)((p->na + RK_I - 1) / RK_I + 1) * 4);
     p->off_off = o; o = al(o + (size_t)(p->nb + 2) * 4);
     p->off_lists = o; o = al(o + (size_t)p->na * 4);
+    p->off_parts = o; o = al(o + (p->na <= kRankMax ? (size_t)kRankParts * p->na * 4 : 0));      // partial ranks [parts][na]
     size_t cub = 0;
     (void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, cub, (const float*)nullptr, (float*)nullptr, (const int*)nullptr,
                                                  (int*)nullptr, p->na);
@@ -994,8 +1114,9 @@ int sttm_tome_step(const void* x_, const float* size, const int64_t* idx, int n,
     int* off = reinterpret_cast<int*>(ws + p.off_off);
     int* lists = reinterpret_cast<int*>(ws + p.off_lists);
 
-    (void)hipMemsetAsync(best, 0, (size_t)p.na * 8, stream);
-    (void)hipMemsetAsync(cnt, 0, p.off_off - p.off_cnt, stream);      // cnt and cur
+    int* rank = reinterpret_cast<int*>(ws + p.off_parts);
+    int* arrive = reinterpret_cast<int*>(ws + p.off_arrive);
+    (void)hipMemsetAsync(best, 0, p.off_off - p.off_best, stream);     // best, cnt, cur, rank, arrive: one contiguous region
     const int ngrid = [&] { int g = (n + 3) / 4; return g > 8192 ? 8192 : g; }();
     // j-split: the grid is itiles*jsplit workgroups of ceil(jtiles/jsplit) tile products each, `resident` per CU.
     // Pick the split with the smallest per-CU critical path  ceil(WGs / slots) * tiles-per-WG  (a 588-WG grid on 512
@@ -1098,12 +1219,24 @@ int sttm_tome_step(const void* x_, const float* size, const int64_t* idx, int n,
         if (dtype == STTM_BF16) STTM_TOME_16(bf16_t); else STTM_TOME_16(f16_t);
 #undef STTM_TOME_16
     }
-    hipLaunchKernelGGL(k_tome_unpack, dim3((p.na + 255) / 256), dim3(256), 0, stream, best, p.na, nmax, nidx, iota);
-    size_t cub = p.cub_bytes;
-    (void)hipcub::DeviceRadixSort::SortPairsDescending(ws + p.off_cub, cub, nmax, keys, iota, order, p.na, 0, 32, stream);
-    hipLaunchKernelGGL(k_tome_count, dim3((r + 255) / 256), dim3(256), 0, stream, order, nidx, r, cnt);
-    hipLaunchKernelGGL(k_tome_scan, dim3(1), dim3(1024), 0, stream, cnt, p.nb, off);
-    hipLaunchKernelGGL(k_tome_fill, dim3((r + 255) / 256), dim3(256), 0, stream, order, nidx, r, off, cur, lists);
+    if (p.na <= kRankMax && tome_rank_mode() != 1) {
+        // ranking by counting (+ the scan, in its last workgroup) and the list fill (round 4): 2 launches instead of 8
+        const int iblocks = (p.na + RK_I - 1) / RK_I;
+        int js = (8 * n_cu + iblocks - 1) / iblocks;                    // ~8 four-wave workgroups per CU: the scalar key loads of a wave
+        const int max_js = (p.na + 255) / 256;                          // are not pipelined, other waves cover them
+        if (js > max_js) js = max_js;
+        if (js > kRankParts) js = kRankParts;
+        if (js < 1) js = 1;
+        hipLaunchKernelGGL(k_tome_rank, dim3(iblocks * js), dim3(RK_I), 0, stream, best, p.na, js, r, rank, arrive, nmax, nidx, order, cnt, p.nb, off);
+        hipLaunchKernelGGL(k_tome_fill, dim3((r + 255) / 256), dim3(256), 0, stream, order, nidx, r, off, cur, lists);
+    } else {
+        hipLaunchKernelGGL(k_tome_unpack, dim3((p.na + 255) / 256), dim3(256), 0, stream, best, p.na, nmax, nidx, iota);
+        size_t cub = p.cub_bytes;
+        (void)hipcub::DeviceRadixSort::SortPairsDescending(ws + p.off_cub, cub, nmax, keys, iota, order, p.na, 0, 32, stream);
+        hipLaunchKernelGGL(k_tome_count, dim3((r + 255) / 256), dim3(256), 0, stream, order, nidx, r, cnt);
+        hipLaunchKernelGGL(k_tome_scan, dim3(1), dim3(1024), 0, stream, cnt, p.nb, off);
+        hipLaunchKernelGGL(k_tome_fill, dim3((r + 255) / 256), dim3(256), 0, stream, order, nidx, r, off, cur, lists);
+    }
     {
         int grid = (n - r + 3) / 4; if (grid > 8192) grid = 8192;
 #define STTM_TOME_MERGE(TT, VV) hipLaunchKernelGGL((k_tome_merge<TT, VV>), dim3(grid), dim3(256), 0, stream, x_, size, idx, n, C, p.na, p.nb, r, order, off, lists, x_out_, size_out, idx_out)

@@ -14,7 +14,7 @@ for ratio in (0.5, 0.7, 0.85):
     get_tome_features(x, ratio, "video")
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    n_it = 5
+    n_it = int(os.environ.get("N_IT", "5"))
     for _ in range(n_it):
         f, i = get_tome_features(x, ratio, "video")
     torch.cuda.synchronize()
