@@ -228,7 +228,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // Butterfly "transpose-reduce": every lane enters with N partial values, and leaves with the full
 // 64-lane total of ONE of them (value index reduce_slot<N>(lane); lanes whose slot is padding get
 // reduce_valid == false).  Costs ~N shuffles instead of 6*N.
-template <int N>
+template <int N, int SWAP = 0>      // SWAP: 0 = selects + ds_bpermute at every stage, 1 = lane swap at stage 32, 2 = at stages 32 and 16
 __device__ __forceinline__ float wave_reduce_many(float (&v)[N], int lane) {
     static_assert(N >= 1 && N <= 64, "one result per lane");
     int n = N;
@@ -240,6 +240,23 @@ __device__ __forceinline__ float wave_reduce_many(float (&v)[N], int lane) {
         for (int i = 0; i < half; ++i) {
             const float lo = v[i];
             const float hi = (i + half < n) ? v[i + half] : 0.f;
+            if constexpr (SWAP > 0) {
+            // SWAP (16-bit kernels, where the registers allow it -- the 128-register fp32 kernel spills 52 bytes with it):
+            // stages 32 and 16 as ONE lane-swap instruction + one add per output instead of two selects + a ds_bpermute + an add:
+            // v_permlane32_swap exchanges the upper half of `lo` with the lower half of `hi`, v_permlane16_swap the odd 16-lane
+            // rows of `lo` with the even rows of `hi`; afterwards the two registers hold exactly (own kept value, partner's sent
+            // value) in every lane -- the same two operands as the select form, so the sums are bit-identical.
+            if (m == 32) {
+                const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+                v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                continue;
+            }
+            if (m == 16 && SWAP > 1) {
+                const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+                v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                continue;
+            }
+            }
             const float keep = up ? hi : lo;
             const float send = up ? lo : hi;
             v[i] = keep + __shfl_xor(send, m, 64);

@@ -1201,9 +1201,9 @@ int sttm_tome_step(const void* x_, const float* size, const int64_t* idx, int n,
         pick_flat(it, js);
 #ifdef STTM_DEV
         const int abl16 = getenv("STTM_TOME_ABL") ? atoi(getenv("STTM_TOME_ABL")) : 0;
-        constexpr int ABL16A = 3, ABL16B = 4;
+        constexpr int ABL16A = 3, ABL16B = 4, ABL16C = 5;
 #else
-        constexpr int abl16 = 0, ABL16A = 0, ABL16B = 0;
+        constexpr int abl16 = 0, ABL16A = 0, ABL16B = 0, ABL16C = 0;
 #endif
 #define STTM_TOME_16(TT)                                                                                                            \
         do {                                                                                                                        \
@@ -1213,6 +1213,7 @@ int sttm_tome_step(const void* x_, const float* size, const int64_t* idx, int n,
                 hipLaunchKernelGGL((k_tome_normalize16<TT, 1>), dim3(ngrid), dim3(256), 0, stream, x_, n, C, n_head, p.D, p.Dp, ap, bp); \
             if (big && abl16 == 3) hipLaunchKernelGGL((k_tome_match_glds<1, 1, TT, ABL16A>), dim3(js ? it * js : it), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best); \
             else if (big && abl16 == 4) hipLaunchKernelGGL((k_tome_match_glds<1, 1, TT, ABL16B>), dim3(js ? it * js : it), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best); \
+            else if (big && abl16 == 5) hipLaunchKernelGGL((k_tome_match_glds<1, 1, TT, ABL16C>), dim3(js ? it * js : it), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best); \
             else if (big) hipLaunchKernelGGL((k_tome_match_glds<1, 1, TT>), dim3(js ? it * js : it), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best); \
             else hipLaunchKernelGGL(k_tome_match16<TT>, dim3(itiles * jsplit), dim3(256), 0, stream, ap, bp, p.na, p.nb, p.Dp, jsplit, best); \
         } while (0)
