@@ -99,6 +99,18 @@ int sttm_quadtree_merge(const void* x, int64_t stride_t, int64_t stride_c, int64
                         void* stream);
 
 /*
+ * The spatial stage alone (SURVEY Appendix E's `sttm_quadtree_spatial`): quadtree_build_video with temporal_thresh <= 0 -- per-frame
+ * pyramid, split decisions and node emission (quadtree_builder.py:85-215), nodes in (t, y1, x1) order.  Same buffers as
+ * sttm_quadtree_merge; counts[STTM_CNT_OUT] = number of nodes.  (The temporal stage has no stand-alone entry point: it reads the
+ * node tables the spatial kernel leaves in the workspace -- root-cell node lists, inverse norms, default labels -- not a caller's
+ * node list; cross_frame_node_merging_fast is never called on its own by the reference's L1, quadtree_builder.py:217-223.)
+ */
+int sttm_quadtree_spatial(const void* x, int64_t stride_t, int64_t stride_c, int64_t stride_h, int64_t stride_w,
+                          int T, int C, int H, int W, int dtype, float threshold, int root_level, int weighted_avg, int head_dim,
+                          void* workspace, size_t workspace_bytes, void* feat_out, int32_t* npatch_out, int32_t* tlbr_out, int32_t* counts,
+                          void* stream);
+
+/*
  * Same merge, but the counts are ALSO published into `counts_host` -- int32[STTM_CNT_SLOTS] of pinned, device-mapped
  * host memory -- by the kernel that computes N' (the one before the feature gather), with slot STTM_CNT_SLOTS-1 set
  * to `seq` last (system-scope release).  sttm_wait_counts waits (no HIP call: a short spin, then a yielding poll) until

@@ -525,6 +525,15 @@ int sttm_quadtree_merge(const void* x, int64_t stride_t, int64_t stride_c, int64
                                      tlbr_out, counts, nullptr, 0, nullptr, stream_);
 }
 
+int sttm_quadtree_spatial(const void* x, int64_t stride_t, int64_t stride_c, int64_t stride_h, int64_t stride_w,
+                          int T, int C, int H, int W, int dtype, float threshold, int root_level, int weighted_avg, int head_dim,
+                          void* workspace, size_t workspace_bytes, void* feat_out, int32_t* npatch_out, int32_t* tlbr_out, int32_t* counts,
+                          void* stream_) {
+    // the spatial stage alone = the merge with the temporal stage switched off (quadtree_builder.py:217: `if temporal_thresh > 0`)
+    return sttm_quadtree_merge(x, stride_t, stride_c, stride_h, stride_w, T, C, H, W, dtype, threshold, -1.0f, root_level, weighted_avg,
+                               head_dim, 0, workspace, workspace_bytes, feat_out, npatch_out, tlbr_out, counts, stream_);
+}
+
 int sttm_quadtree_merge_async(const void* x, int64_t stride_t, int64_t stride_c, int64_t stride_h, int64_t stride_w,
                               int T, int C, int H, int W, int dtype,
                               float threshold, float temporal_thresh, int root_level, int weighted_avg, int head_dim, int slow_ver,

@@ -228,7 +228,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 // Butterfly "transpose-reduce": every lane enters with N partial values, and leaves with the full
 // 64-lane total of ONE of them (value index reduce_slot<N>(lane); lanes whose slot is padding get
 // reduce_valid == false).  Costs ~N shuffles instead of 6*N.
-template <int N, int SWAP = 0>      // SWAP: 0 = selects + ds_bpermute at every stage, 1 = lane swap at stage 32, 2 = at stages 32 and 16
+template <int N, int SWAP = 0>      // SWAP: 0 = selects + ds_bpermute at every stage, 1 = lane swap at stage 32, 2 = at stages 32 and 16,
+                                    //       3 = the same through in-place inline asm (no copies for the tied operands: the 128-register fp32 kernel)
 __device__ __forceinline__ float wave_reduce_many(float (&v)[N], int lane) {
     static_assert(N >= 1 && N <= 64, "one result per lane");
     int n = N;
@@ -247,13 +248,25 @@ __device__ __forceinline__ float wave_reduce_many(float (&v)[N], int lane) {
             // rows of `lo` with the even rows of `hi`; afterwards the two registers hold exactly (own kept value, partner's sent
             // value) in every lane -- the same two operands as the select form, so the sums are bit-identical.
             if (m == 32) {
-                const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
-                v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                if constexpr (SWAP >= 3) {            // in place (inline asm: no copies for the tied operands)
+                    float a = lo, b = hi;
+                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));     // (the hazard recogniser does not see inside: wait states by hand)
+                    v[i] = a + b;
+                } else {
+                    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+                    v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                }
                 continue;
             }
             if (m == 16 && SWAP > 1) {
-                const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
-                v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                if constexpr (SWAP >= 3) {
+                    float a = lo, b = hi;
+                    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+                    v[i] = a + b;
+                } else {
+                    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+                    v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                }
                 continue;
             }
             }

@@ -329,6 +329,34 @@ def test_pos_embs_from_two_threads_on_one_stream():
         assert torch.equal(out[3][0], ref[3][0]) and torch.equal(out[3][1], ref[3][1])
 
 
+def test_stand_alone_spatial_entry_point():
+    """sttm_quadtree_spatial through ctypes: the spatial stage alone == the merge with temporal_thresh <= 0
+    == the oracle's spatial-only result."""
+    from oracle import sttm_oracle as O
+    from sttm_amd import _lib
+    from sttm_amd.synth import synth_video
+    lib = _lib.load()
+    dev = _dev()
+    T, C, H, W, root = 6, 256, 14, 14, 1
+    xc = synth_video(T, C, H, W, seed=61)
+    exp = O.get_quadtree_features(xc, 0.85, -1.0, root)
+    x = xc.to(dev)                                            # logical [T, C, H, W], channels-last memory
+    N = T * H * W
+    nbytes = lib.sttm_quadtree_workspace_bytes(T, H, W, C, _lib.STTM_F32, root)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    feat = torch.empty((N, C), device=dev)
+    npatch = torch.empty(N, dtype=torch.int32, device=dev)
+    tlbr = torch.empty((N, 5), dtype=torch.int32, device=dev)
+    counts = torch.zeros(_lib.CNT_SLOTS, dtype=torch.int32, device=dev)
+    rc = lib.sttm_quadtree_spatial(x.data_ptr(), x.stride(0), x.stride(1), x.stride(2), x.stride(3), T, C, H, W, _lib.STTM_F32, 0.85, root, 0, 0,
+                                   ws.data_ptr(), nbytes, feat.data_ptr(), npatch.data_ptr(), tlbr.data_ptr(), counts.data_ptr(),
+                                   torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, _lib.last_error()
+    torch.cuda.synchronize()
+    n = int(counts[_lib.CNT_OUT])
+    _check((feat[:n], npatch[:n], tlbr[:n]), exp, FP32_TOL, "sttm_quadtree_spatial")
+
+
 def test_batched_extension_equals_per_video_calls():
     """get_quadtree_features_batch (sttm_quadtree_merge_batch: same-shaped videos share one set of launches) returns exactly what
     per-video calls return; mixed shapes are grouped, more than STTM_BATCH_MAX videos of a shape are issued in groups."""
