@@ -15,6 +15,8 @@ SHAPES = {
     "c4": (128, 1024, 20, 36, torch.float32, 0.85, 0.60),
     "c5": (180, 1024, 14, 14, torch.float32, 0.94, 0.82),
     "c2": (64, 1024, 14, 14, torch.float32, 0.85, 0.65),
+    "c4b": (128, 1024, 18, 26, torch.float32, 0.85, 0.60),
+    "c4c": (128, 1024, 13, 24, torch.float32, 0.85, 0.60),
     "t256": (256, 1024, 14, 14, torch.float32, 0.85, 0.55),
     "wide": (128, 8192, 14, 14, torch.bfloat16, 0.85, 0.55),
     "bf16n": (128, 2048, 14, 14, torch.bfloat16, 0.85, 0.55),
@@ -44,7 +46,7 @@ def main():
     specs = args or ["default"]
     for sh in shapes:
         T, C, H, W, dt, thr, tthr = SHAPES[sh]
-        P = 8 if sh not in ("c4", "wide", "t256") else 4
+        P = 8 if sh not in ("c4", "c4b", "wide", "t256") else 4
         pool = [synth_video(T, C, H, W, seed=i, dtype=dt, device=dev, gen_device=dev) for i in range(P)]
         configure("default")
         ref = [get_quadtree_features(x, thr, tthr, 1) for x in pool]
