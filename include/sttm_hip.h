@@ -160,6 +160,9 @@ typedef struct sttm_merge_args {
     uint64_t* early_host;
     void* const* events; void* stream;
     int32_t flags;                   /* ABI v6: per-call options, STTM_FLAG_* (0 = defaults) */
+    int32_t* idx_out;                /* ABI v6: NULL, or [T*H*W] int32: t*H*W + y1*W + x1 of every merged token, rows [0, N') -- the
+                                        merged_token_1d_idx the patched forward derives from tlbr (quadtree_attn_monkey_patch.py:103-104),
+                                        written by the group-mean kernel instead of by three elementwise launches of the caller */
 } sttm_merge_args;
 int sttm_quadtree_merge_packed(sttm_merge_args* args);
 /* Waits until either all n_early column words carry `seq` (then out[0] = N', out[1] = overflow flags in the encoding of

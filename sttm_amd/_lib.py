@@ -65,7 +65,7 @@ class MergeArgs(ctypes.Structure):
                 ("workspace", _vp), ("workspace_bytes", _sz),
                 ("feat_out", _vp), ("npatch_out", _vp), ("tlbr_out", _vp), ("counts", _vp),
                 ("counts_host", _vp), ("seq", ctypes.c_int32), ("n_early", ctypes.c_int32), ("early_host", _vp),
-                ("events", _vp), ("stream", _vp), ("flags", ctypes.c_int32)]
+                ("events", _vp), ("stream", _vp), ("flags", ctypes.c_int32), ("idx_out", _vp)]
 
 
 _lib = None

@@ -317,7 +317,7 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
                 void* workspace, size_t workspace_stride,
                 void* const* feat_out, int32_t* const* npatch_out, int32_t* const* tlbr_out, int32_t* counts,
                 int32_t* counts_host, int seq, void* const* events, hipStream_t stream,
-                uint64_t* early_host = nullptr, int* n_early = nullptr, int flags = 0) {
+                uint64_t* early_host = nullptr, int* n_early = nullptr, int flags = 0, int32_t* idx_out = nullptr) {
     if (n_early) *n_early = 0;
     if (!x || !workspace || !feat_out || !npatch_out || !tlbr_out || !counts) return fail(STTM_ERR_ARG, "null pointer argument");
     if (T < 1 || C < 1) return fail(STTM_ERR_ARG, "T and C must be positive");
@@ -428,6 +428,7 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
         *n_early = p.R;
     }
     ta.feat_out = feat_out[0]; ta.npatch_out = npatch_out[0]; ta.tlbr_out = tlbr_out[0];
+    ta.idx_out = nv == 1 ? idx_out : nullptr;
 #ifdef STTM_DEV
     sa.dev = g_dev; ta.dev = g_dev;
 #endif
@@ -555,7 +556,7 @@ int sttm_quadtree_merge_packed(sttm_merge_args* g) {
     const int rc = merge_group(1, &x, g->stride_t, g->stride_c, g->stride_h, g->stride_w, g->T, g->C, g->H, g->W, g->dtype, g->threshold,
                                g->temporal_thresh, g->root_level, g->weighted_avg, g->head_dim, g->slow_ver, g->workspace, g->workspace_bytes,
                                &feat, &np, &tl, g->counts, g->counts_host, g->seq, g->events, reinterpret_cast<hipStream_t>(g->stream),
-                               g->early_host, &n_early, g->flags);
+                               g->early_host, &n_early, g->flags, g->idx_out);
     g->n_early = n_early;
     return rc;
 }

@@ -130,6 +130,7 @@ struct TemporalArgs {
     void* feat_out;
     int32_t* npatch_out;
     int32_t* tlbr_out;
+    int32_t* idx_out;         // optional [T*H*W] int32: t*H*W + y1*W + x1 of every merged token (the hook's merged_token_1d_idx); single video only
 #ifdef STTM_DEV
     DevHooks dev;
 #endif

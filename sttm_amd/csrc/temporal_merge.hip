@@ -1343,7 +1343,7 @@ __device__ __forceinline__ void store_pack_buf(__amdgpu_buffer_rsrc_t rs, uint32
 
 struct GmRow { int p, out, n; uint32_t mt, geo; };       // wave-uniform: slot in the frame, output row, group size, box, column geometry
 
-template <typename T, int VEC, int OCC>
+template <typename T, int VEC, int OCC, bool MEM2>
 __global__ void __launch_bounds__(256, OCC) k_group_mean(const TemporalArgs a0, const BatchPtrs bp) {
     TemporalArgs a = a0;
     rebase(a, bp, blockIdx.y);
@@ -1462,22 +1462,44 @@ __global__ void __launch_bounds__(256, OCC) k_group_mean(const TemporalArgs a0, 
                             const int my1 = a.W > 1 ? (int)__umulhi((unsigned)rem, magicW) : rem, mx1 = rem - my1 * a.W;
                             ar = ((int)(q >> 16) - my1) * ((int)(q & 0xffff) - mx1);
                         }
+                        // MEM2: members two at a time, both rows requested before the first is added (the sums keep their ascending
+                        // order; one member per round trip makes a group of n a chain of n - 1 dependent loads -- heavy merges,
+                        // e.g. the 20 x 36 grids at 12 % kept tokens, spend most of this kernel there: 41.6 -> 37.0 us).  It costs
+                        // 13 registers, i.e. a wave per SIMD (5 instead of 6): on the 14 x 14 headline, where a group has 1.7 extra
+                        // members on average, that is +0.3 us, so the launch picks it for root cells of more than 16 leaves only.
                         while (mm) {
-                            const int k = __ffsll((long long)mm) - 1;
+                            const int k0 = __ffsll((long long)mm) - 1;
                             mm &= mm - 1ull;
-                            const int mr = __builtin_amdgcn_readlane(mrow, k), ak = __builtin_amdgcn_readlane(ar, k);
-                            const void* sm = (ak == 1 && a.xrows) ? a.xrows : a.S;
-                            const __amdgpu_buffer_rsrc_t dm = row_desc(sm, mr, cb0);
-                            Pack<T, VEC> qv[U];
+                            const bool two = MEM2 && mm != 0ull;
+                            const int k1 = two ? __ffsll((long long)mm) - 1 : k0;
+                            if (two) mm &= mm - 1ull;
+                            const int mr0 = __builtin_amdgcn_readlane(mrow, k0), ak0 = __builtin_amdgcn_readlane(ar, k0);
+                            const int mr1 = __builtin_amdgcn_readlane(mrow, k1), ak1 = __builtin_amdgcn_readlane(ar, k1);
+                            const __amdgpu_buffer_rsrc_t dm0 = row_desc((ak0 == 1 && a.xrows) ? a.xrows : a.S, mr0, cb0);
+                            const __amdgpu_buffer_rsrc_t dm1 = row_desc((ak1 == 1 && a.xrows) ? a.xrows : a.S, mr1, cb0);
+                            Pack<T, VEC> qv[U], qw[U];
 #pragma unroll
-                            for (int u = 0; u < U; ++u) qv[u] = load_pack_buf<T, VEC>(dm, (uint32_t)((u * 64 + lane) * VEC * eb));
+                            for (int u = 0; u < U; ++u) qv[u] = load_pack_buf<T, VEC>(dm0, (uint32_t)((u * 64 + lane) * VEC * eb));
+                            if (two) {
+#pragma unroll
+                                for (int u = 0; u < U; ++u) qw[u] = load_pack_buf<T, VEC>(dm1, (uint32_t)((u * 64 + lane) * VEC * eb));
+                            }
 #pragma unroll
                             for (int u = 0; u < U; ++u) {
                                 const Pack<T, VEC> prev = acc[u];
                                 pack_fill(acc[u], [&](int e) { return prev.get(e) + qv[u].get(e); });
                             }
                             ++found;
-                            if (cb0 == 0) patches += ak;
+                            if (cb0 == 0) patches += ak0;
+                            if (two) {
+#pragma unroll
+                                for (int u = 0; u < U; ++u) {
+                                    const Pack<T, VEC> prev = acc[u];
+                                    pack_fill(acc[u], [&](int e) { return prev.get(e) + qw[u].get(e); });
+                                }
+                                ++found;
+                                if (cb0 == 0) patches += ak1;
+                            }
                         }
                     }
                 }
@@ -1494,6 +1516,7 @@ __global__ void __launch_bounds__(256, OCC) k_group_mean(const TemporalArgs a0, 
                 for (int u = 0; u < U; ++u) store_pack_buf<T, VEC>(dout, (uint32_t)((u * 64 + lane) * VEC * eb), acc[u]);
             }
             if (a.npatch_out && lane == 0) {
+                if (a.idx_out) a.idx_out[r.out] = origin;
                 a.npatch_out[r.out] = patches;
                 int32_t* o = a.tlbr_out + (int64_t)r.out * 5;
                 o[0] = t; o[1] = y1; o[2] = x1; o[3] = y2; o[4] = x2;
@@ -1512,7 +1535,9 @@ __global__ void __launch_bounds__(256, OCC) k_group_mean(const TemporalArgs a0, 
 
 hipError_t launch_group_mean(const TemporalArgs& a, const BatchPtrs& bp, int n_videos, hipStream_t stream) {
     const int grid = a.T * a.gm_split;
-#define STTM_LAUNCH_GM(TT, VV) hipLaunchKernelGGL((k_group_mean<TT, VV, 6>), dim3(grid, n_videos), dim3(256), 0, stream, a, bp)
+    const bool mem2 = a.max_slots > 16 * a.T;          // root cells of more than 16 leaves (4-level trees and deeper)
+#define STTM_LAUNCH_GM(TT, VV) do { if (mem2) hipLaunchKernelGGL((k_group_mean<TT, VV, 5, true>), dim3(grid, n_videos), dim3(256), 0, stream, a, bp); \
+                                    else hipLaunchKernelGGL((k_group_mean<TT, VV, 6, false>), dim3(grid, n_videos), dim3(256), 0, stream, a, bp); } while (0)
     if (a.dtype == STTM_F32) {
         if (a.vec == 8) STTM_LAUNCH_GM(float, 8); else if (a.vec == 4) STTM_LAUNCH_GM(float, 4); else if (a.vec == 2) STTM_LAUNCH_GM(float, 2); else STTM_LAUNCH_GM(float, 1);
     } else if (a.dtype == STTM_BF16) {

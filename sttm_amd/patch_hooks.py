@@ -31,13 +31,19 @@ def _merge_concat(hidden_states, start, length, video, merge_fn, merge_into_fn, 
     sys_f, _, inst_f = split_prompt(hidden_states, start, length)
     if merge_into_fn is None or hidden_states.size(0) != 1:
         feat, npatch, tlbr = merge_fn(video, *args, **kwargs)
-        return torch.cat([sys_f, feat.unsqueeze(0), inst_f], dim=1), tlbr
+        return torch.cat([sys_f, feat.unsqueeze(0), inst_f], dim=1), tlbr, None
     new = torch.empty_like(hidden_states, memory_format=torch.contiguous_format)
     new[:, :start].copy_(sys_f)
-    feat, npatch, tlbr = merge_into_fn(new[0, start:], video, *args, **kwargs)
+    # the kernels also write merged_token_1d_idx (t*H*W + y1*W + x1, :103-104) when the merge function offers it: three
+    # elementwise launches of the caller less
+    idx = None
+    if getattr(merge_into_fn, "returns_idx", False):
+        feat, npatch, tlbr, idx = merge_into_fn(new[0, start:], video, *args, return_idx=True, **kwargs)
+    else:
+        feat, npatch, tlbr = merge_into_fn(new[0, start:], video, *args, **kwargs)
     n = feat.size(0)
     new[:, start + n:start + n + inst_f.size(1)].copy_(inst_f)
-    return new[:, :start + n + inst_f.size(1)], tlbr
+    return new[:, :start + n + inst_f.size(1)], tlbr, idx
 
 
 def quadtree_merge_llava(hidden_states, position_ids, start, length, T, merge_fn, threshold, temporal_thresh,
@@ -45,10 +51,11 @@ def quadtree_merge_llava(hidden_states, position_ids, start, length, T, merge_fn
     """Returns (merged hidden_states [1, S', C], position_ids[:, :S'], merged_token_1d_idx)."""
     H = W = int(math.sqrt(length // T))                                   # :97 (needs mm_newline_position=no_token)
     video = _video_view(hidden_states[0, start:start + length], T, H, W)
-    merged, tlbr = _merge_concat(hidden_states, start, length, video, merge_fn, merge_into_fn,
-                                 (threshold, temporal_thresh, root_level, weighted_avg),
-                                 dict(slow_ver=slow_ver, head_dim=head_dim))
-    idx = tlbr[:, 0] * (H * W) + tlbr[:, 1] * W + tlbr[:, 2]              # :103-104
+    merged, tlbr, idx = _merge_concat(hidden_states, start, length, video, merge_fn, merge_into_fn,
+                                      (threshold, temporal_thresh, root_level, weighted_avg),
+                                      dict(slow_ver=slow_ver, head_dim=head_dim))
+    if idx is None:
+        idx = tlbr[:, 0] * (H * W) + tlbr[:, 1] * W + tlbr[:, 2]          # :103-104
     return merged, position_ids[:, :merged.size(1)], idx                   # :114 (truncate, not gather)
 
 
@@ -58,9 +65,10 @@ def quadtree_merge_qwen2vl(hidden_states, position_ids, start, length, T, H, W, 
     Returns (merged hidden_states, position_ids, cache_position, merged_token_1d_idx)."""
     end = start + length
     video = _video_view(hidden_states[0, start:end], T, H, W)
-    merged, tlbr = _merge_concat(hidden_states, start, length, video, merge_fn, merge_into_fn,
-                                 (threshold, temporal_thresh, root_level, weighted_avg), dict(slow_ver=slow_ver))
-    idx = tlbr[:, 0] * (H * W) + tlbr[:, 1] * W + tlbr[:, 2]
+    merged, tlbr, idx = _merge_concat(hidden_states, start, length, video, merge_fn, merge_into_fn,
+                                      (threshold, temporal_thresh, root_level, weighted_avg), dict(slow_ver=slow_ver))
+    if idx is None:
+        idx = tlbr[:, 0] * (H * W) + tlbr[:, 1] * W + tlbr[:, 2]
     vis_pos = position_ids[:, :, start:end][:, :, idx.long()]
     pos = torch.cat([position_ids[:, :, :start], vis_pos, position_ids[:, :, end:]], dim=-1)
     cache_position = torch.arange(merged.size(1), device=merged.device, dtype=torch.int)      # :114

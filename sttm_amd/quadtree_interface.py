@@ -252,7 +252,7 @@ def _acquire_state(dev):
 
 
 def quadtree_merge_raw(x, threshold, temporal_thresh, root_level, weighted_avg, head_dim, slow_ver=False, return_ctx=False,
-                       feat_dest=None, events=None, side_tensors=None, side_sum_mode=False):
+                       feat_dest=None, events=None, side_tensors=None, side_sum_mode=False, want_idx=False):
     """Launch the merge of one video and return the worst-case-sized outputs plus the host counts (only the slots CNT_OUT and
     CNT_OVERFLOW are filled in on the host; the diagnostic counters stay in the device `counts` tensor of the returned context
     and are complete once the stream has drained).
@@ -262,6 +262,8 @@ def quadtree_merge_raw(x, threshold, temporal_thresh, root_level, weighted_avg, 
     nodes and groups of THIS merge with sttm_quadtree_apply -- inside the same critical section: the apply reads "the merge that
     ran last on this stream with this workspace", so no other host thread on the stream may get in between.  Their pooled
     [T*H*W, Cv] outputs (rows [0, N') valid) are appended to the result as a list.
+    want_idx: also return the merged tokens' 1-d indices t*H*W + y1*W + x1 (int32 [T*H*W], rows [0, N') valid), written by the
+    group-mean kernel -- appended last.
 
     Host path (round 3): the device chain of one call is ~80 us and the next call cannot be issued before this one knows N', so
     every microsecond between "N' arrived" and "next spatial kernel submitted" is device idle time.  Hence: no device context
@@ -280,18 +282,18 @@ def quadtree_merge_raw(x, threshold, temporal_thresh, root_level, weighted_avg, 
     if idx is None or torch.cuda.current_device() != idx:
         with torch.cuda.device(dev):
             return _merge_on_current_device(x, dtype, threshold, temporal_thresh, root_level, weighted_avg, head_dim, slow_ver,
-                                            return_ctx, feat_dest, events, side_tensors, side_sum_mode)
+                                            return_ctx, feat_dest, events, side_tensors, side_sum_mode, want_idx)
     return _merge_on_current_device(x, dtype, threshold, temporal_thresh, root_level, weighted_avg, head_dim, slow_ver,
-                                    return_ctx, feat_dest, events, side_tensors, side_sum_mode)
+                                    return_ctx, feat_dest, events, side_tensors, side_sum_mode, want_idx)
 
 
 def _merge_on_current_device(x, dtype, threshold, temporal_thresh, root_level, weighted_avg, head_dim, slow_ver, return_ctx,
-                             feat_dest, events, side_tensors, side_sum_mode):
+                             feat_dest, events, side_tensors, side_sum_mode, want_idx=False):
     st = _acquire_state(x.device)
     try:
         out = _with_barrier_retry(st, lambda flags: _merge_locked(st, x, dtype, threshold, temporal_thresh, root_level, weighted_avg,
-                                                                   head_dim, slow_ver, feat_dest, events, flags))
-        feat, npatch, tlbr, cnt, xc = out
+                                                                   head_dim, slow_ver, feat_dest, events, flags, want_idx))
+        feat, npatch, tlbr, cnt, xc, idx1d = out
         ctx = (xc, st.ws, st.counts, dtype, _StreamHandle(st.handle, x.device))
         sides = None
         if side_tensors is not None:
@@ -303,10 +305,13 @@ def _merge_on_current_device(x, dtype, threshold, temporal_thresh, root_level, w
         res += (ctx,)
     if sides is not None:
         res += (sides,)
+    if want_idx:
+        res += (idx1d,)
     return res
 
 
-def _merge_locked(st, x, dtype, threshold, temporal_thresh, root_level, weighted_avg, head_dim, slow_ver, feat_dest, events, flags):
+def _merge_locked(st, x, dtype, threshold, temporal_thresh, root_level, weighted_avg, head_dim, slow_ver, feat_dest, events, flags,
+                  want_idx=False):
     """One merge on the stream state `st`, whose lock the caller holds."""
     lib = _lib.load()
     dev = x.device
@@ -344,6 +349,8 @@ def _merge_locked(st, x, dtype, threshold, temporal_thresh, root_level, weighted
             raise ValueError("feat_dest must be a contiguous, 16-byte aligned [rows, C] tensor of the input's dtype and device")
     npatch = torch.empty(N, dtype=torch.int32, device=dev)
     tlbr = torch.empty((N, 5), dtype=torch.int32, device=dev)
+    idx1d = torch.empty(N, dtype=torch.int32, device=dev) if want_idx else None
+    a.idx_out = idx1d.data_ptr() if want_idx else None
     seq = _next_seq()
     a.x, a.feat_out, a.npatch_out, a.tlbr_out, a.seq = ptr, feat.data_ptr(), npatch.data_ptr(), tlbr.data_ptr(), seq
     a.events = events.pointer() if events is not None else None
@@ -366,7 +373,7 @@ def _merge_locked(st, x, dtype, threshold, temporal_thresh, root_level, weighted
     cnt[_lib.CNT_OUT], cnt[_lib.CNT_OVERFLOW] = n_out, ovf
     if ovf:
         _check_overflow(ovf, cnt)
-    return feat, npatch, tlbr, cnt, x
+    return feat, npatch, tlbr, cnt, x, idx1d
 
 
 class _StreamHandle:
@@ -524,19 +531,25 @@ def get_quadtree_features(_video_feature, threshold, temporal_thresh=-1.0, root_
 
 
 def get_quadtree_features_into(dest, _video_feature, threshold, temporal_thresh=-1.0, root_level=0, weighted_avg=False,
-                               slow_ver=False, head_dim=None):
+                               slow_ver=False, head_dim=None, return_idx=False):
     """get_quadtree_features with a caller-owned destination: the merged features are written to dest[:N'] directly
     (dest: contiguous [rows >= T*H*W, C] tensor, e.g. a row window of the NEW hidden-state buffer), so the caller's
     `torch.cat([system, merged, instruction])` (quadtree_attn_monkey_patch.py:105) needs no copy of the merged rows.
     Nothing of `dest` beyond row N' is written.  dest must not overlap the input.
-    Returns (dest[:N'], num_patches [N'], tlbr [N', 5])."""
+    Returns (dest[:N'], num_patches [N'], tlbr [N', 5]); with return_idx also the merged tokens' 1-d indices t*H*W + y1*W + x1
+    (int32 [N'], what the hook computes from tlbr at quadtree_attn_monkey_patch.py:103-104), written by the kernels."""
     T, C, H, W = _video_feature.shape
     if dest.dim() != 2 or dest.size(0) < T * H * W:
         raise ValueError("dest must be [rows, C] with room for the worst case (rows >= T*H*W): N' is only known "
                          "after the kernels have run")
-    feat, npatch, tlbr, cnt = quadtree_merge_raw(_video_feature, threshold, temporal_thresh, root_level, weighted_avg,
-                                                 head_dim, slow_ver, feat_dest=dest)
+    out = quadtree_merge_raw(_video_feature, threshold, temporal_thresh, root_level, weighted_avg,
+                             head_dim, slow_ver, feat_dest=dest, want_idx=return_idx)
+    feat, npatch, tlbr, cnt = out[:4]
     n = cnt[_lib.CNT_OUT]
     if _exact_outputs[0]:
-        return feat[:n], npatch[:n].clone(), tlbr[:n].clone()        # (the features already live in the caller's buffer)
-    return feat[:n], npatch[:n], tlbr[:n]
+        res = (feat[:n], npatch[:n].clone(), tlbr[:n].clone())        # (the features already live in the caller's buffer)
+        return res + ((out[4][:n].clone(),) if return_idx else ())
+    return (feat[:n], npatch[:n], tlbr[:n]) + ((out[4][:n],) if return_idx else ())
+
+
+get_quadtree_features_into.returns_idx = True        # patch_hooks._merge_concat asks for merged_token_1d_idx along with the merge

@@ -61,6 +61,9 @@ def test_into_rejects_short_destination_and_leaves_tail_untouched():
     ef, en, et = get_quadtree_features(x, 0.85, 0.55, 1)
     assert f.data_ptr() == dest.data_ptr() and torch.equal(f, ef) and torch.equal(n, en) and torch.equal(t, et)
     assert torch.all(dest[f.shape[0]:] == 7.0)                     # nothing beyond row N' is written
+    # merged_token_1d_idx written by the kernels == the hook's arithmetic on tlbr (quadtree_attn_monkey_patch.py:103-104)
+    f2, n2, t2, idx = get_quadtree_features_into(dest, x, 0.85, 0.55, 1, return_idx=True)
+    assert idx.dtype == torch.int32 and torch.equal(idx, et[:, 0] * 196 + et[:, 1] * 14 + et[:, 2]) and torch.equal(t2, et)
 
 
 def test_patched_qwen2_forward_runs_on_device_and_matches_oracle_glue():
