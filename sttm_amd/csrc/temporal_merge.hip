@@ -342,8 +342,13 @@ __device__ __forceinline__ bool column_labels(const TemporalArgs& a, int r, cons
         };
         // ONE round trip: the length of every pair's list together with its first HEAD entries (a list holds two edges on
         // average; entries past the length are stale).  The thread that reads entry 0 of a longer list walks the rest.
-        constexpr int HEAD = 16, PER = 2;           // (16: a list longer than the prefetched head is walked with dependent loads -- rare now)
-        const int total = nf * HEAD;
+        // HEAD entries of every list are prefetched: 16 for root cells of up to 16 leaves (a list holds two edges on average there),
+        // 64 for larger cells -- on the 20 x 36 / 18 x 26 grids (root cells of 8 x 8 leaves, heavy merging) many lists have 20 - 60
+        // entries and the walk of their tails, one dependent round trip per entry, was 7 - 11 us of the busiest column (round 4).
+        auto gather = [&](auto per_c, const int hl) {
+        constexpr int PER = decltype(per_c)::value;
+        const int HEAD = 1 << hl;
+        const int total = nf << hl;
         for (int j0 = 0; j0 < total; j0 += PER * nt) {
             int val[PER], tt[PER], cn[PER];
             bool ok[PER];
@@ -351,7 +356,7 @@ __device__ __forceinline__ bool column_labels(const TemporalArgs& a, int r, cons
             for (int k = 0; k < PER; ++k) {
                 const int j = j0 + k * nt + tid;
                 const bool in = j < total;
-                const int t = j / HEAD, e = j % HEAD;
+                const int t = j >> hl, e = j & (HEAD - 1);
                 val[k] = (in && e < cap) ? ld_agent(elist + (int64_t)t * cap + e) : 0;
                 cn[k] = in ? ld_agent(ecnt + t) : 0;
                 ok[k] = in && e < cn[k];
@@ -377,11 +382,14 @@ __device__ __forceinline__ bool column_labels(const TemporalArgs& a, int r, cons
 #pragma unroll
             for (int k = 0; k < PER; ++k) {
                 const int j = j0 + k * nt + tid;
-                if (j < total && j % HEAD == 0 && cn[k] > HEAD)
+                if (j < total && (j & (HEAD - 1)) == 0 && cn[k] > HEAD)
                     for (int e = HEAD; e < cn[k] && e < cap; ++e)
                         take(tt[k], ld_agent(elist + (int64_t)tt[k] * cap + e), atomicAdd(&sh->ecount, 1));
             }
         }
+        };
+        if (cap > 32) gather(std::integral_constant<int, 8>{}, 6);
+        else gather(std::integral_constant<int, 2>{}, 4);
         col_sync<GMEM>();
         E = sh->ecount;
         STTM_LBL_TICK(1);

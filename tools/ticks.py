@@ -13,7 +13,8 @@ from sttm_amd.synth import synth_video
 lib = _lib.load()
 lib.sttm_dev_hooks.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
 dev = torch.device("cuda:0")
-T, C, H, W = int(os.environ.get("T", "128")), 1024, 14, 14
+T, C, H, W = int(os.environ.get("T", "128")), 1024, int(os.environ.get("H", "14")), int(os.environ.get("W", "14"))
+THR, TTHR = float(os.environ.get("THR", "0.85")), float(os.environ.get("TTHR", "0.55"))
 k1_wg, k2_wg, col = (int(a) for a in (sys.argv[1:4] + ["0", "0", "0"])[:3])
 x = synth_video(T, C, H, W, seed=1, device=dev, gen_device=dev)
 nbytes = lib.sttm_quadtree_workspace_bytes(T, H, W, C, 0, 1)
@@ -31,11 +32,12 @@ runs = 0
 for it in range(12):
     ticks.zero_()
     rc = lib.sttm_quadtree_merge(x.data_ptr(), x.stride(0), x.stride(1), x.stride(2), x.stride(3), T, C, H, W, 0,
-                                 0.85, 0.55, 1, 0, 0, 0, ws.data_ptr(), nbytes, feat.data_ptr(), npatch.data_ptr(),
+                                 THR, TTHR, 1, 0, 0, 0, ws.data_ptr(), nbytes, feat.data_ptr(), npatch.data_ptr(),
                                  tlbr.data_ptr(), counts.data_ptr(), torch.cuda.current_stream().cuda_stream)
     assert rc == 0, _lib.last_error()
     torch.cuda.synchronize()
     tk = ticks.cpu().tolist()
+    last_counts = counts.cpu().tolist()
     if it < 2:
         continue
     runs += 1
@@ -49,3 +51,5 @@ for base, (title, nm) in names.items():
     for n_, v in zip(nm[1:], acc[base]):
         print(f"  {n_:16s} {v / runs:6.2f}")
     print(f"  {'total':16s} {sum(acc[base]) / runs:6.2f}")
+
+print("counts (nodes, candidates, edges, out, iters, overflow, leafnodes):", last_counts[:7])
