@@ -212,6 +212,7 @@ LABEL_PATHS = [
     dict(pairs_seg=4), dict(pairs_seg=16, pairs_nt=256),   # runs of frame pairs per pair workgroup
     dict(pairs_var=9),                               # the general pair kernel instead of the lean 256-thread form
     dict(no_dense=1),                                # column label stage with compact ids even where the slots fit LDS uncompacted
+    dict(no_dense=2),                                # round 3's form of the slot-indexed label stage (three barriers per iteration)
 ]
 
 
@@ -327,6 +328,24 @@ def test_pos_embs_from_two_threads_on_one_stream():
     for out in got:
         assert all(torch.equal(a, b) for a, b in zip(out[:3], ref[:3]))
         assert torch.equal(out[3][0], ref[3][0]) and torch.equal(out[3][1], ref[3][1])
+
+
+def test_exact_size_outputs_opt_in():
+    """set_exact_outputs(True): the three results are exact-size tensors of their own (the reference returns exact sizes,
+    quadtree_builder.py:198-226), not leading views of the worst-case [T*H*W, C] block; same values."""
+    from sttm_amd import get_quadtree_features, quadtree_interface as QI
+    from sttm_amd.synth import synth_video
+    x = synth_video(8, 128, 14, 14, seed=71).to(_dev())
+    ref = get_quadtree_features(x, 0.85, 0.55, 1)
+    assert ref[0].untyped_storage().nbytes() == 8 * 196 * 128 * 4          # default: a view of the worst-case block
+    try:
+        QI.set_exact_outputs(True)
+        out = get_quadtree_features(x, 0.85, 0.55, 1)
+        n = out[0].shape[0]
+        assert out[0].untyped_storage().nbytes() == n * 128 * 4 and out[2].untyped_storage().nbytes() == n * 5 * 4
+        assert all(torch.equal(a, b) for a, b in zip(out, ref))
+    finally:
+        QI.set_exact_outputs(False)
 
 
 def test_stand_alone_spatial_entry_point():
