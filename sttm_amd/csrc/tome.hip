@@ -837,6 +837,7 @@ __global__ void __launch_bounds__(RK_I) k_tome_rank(const unsigned long long* __
     __shared__ __attribute__((aligned(16))) unsigned tile[RK_I];
     __shared__ int last_sh, all_sh;
     __shared__ int wsum[RK_I / 64];
+    __shared__ int stile[16 * RK_I];            // the closing scan's transpose tile (16 KB)
     const int ib = blockIdx.x / jsplit, js = blockIdx.x - ib * jsplit;
     const int tid = threadIdx.x;
     const int i = ib * RK_I + tid;
@@ -889,7 +890,14 @@ __global__ void __launch_bounds__(RK_I) k_tome_rank(const unsigned long long* __
     if (!last_sh) return;
     if (i < na) {
         int rk = 0;
-        for (int q = 0; q < jsplit; ++q) rk += __hip_atomic_load(rank + (size_t)q * na + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int q0 = 0; q0 < jsplit; q0 += 8) {           // eight independent loads per round trip
+            int pv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                pv[u] = q0 + u < jsplit ? __hip_atomic_load(rank + (size_t)(q0 + u) * na + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rk += pv[u];
+        }
         order[rk] = i;
         unsigned u = (unsigned)(bi >> 32);
         u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
@@ -906,23 +914,45 @@ __global__ void __launch_bounds__(RK_I) k_tome_rank(const unsigned long long* __
     if (tid == 0) all_sh = __hip_atomic_fetch_add(arrive + iblocks, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == iblocks - 1;
     __syncthreads();
     if (!all_sh) return;
+    // chunks of 16 x 256 counts: sixteen independent coalesced loads per thread (ONE round trip per chunk; a thread walking its own
+    // contiguous run did one dependent round trip per element -- 2 x 49 of them at T = 128), transposed through LDS so that every
+    // thread scans sixteen CONTIGUOUS counts, then the usual wave / workgroup prefix and a running carry
     const int lane = tid & 63, wave = tid >> 6;
-    const int per = (nb + RK_I - 1) / RK_I;
-    const int lo = min(tid * per, nb), hi = min(lo + per, nb);
-    int total = 0;
-    for (int q = lo; q < hi; ++q) total += __hip_atomic_load(cnt + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int inc = total;
+    constexpr int PERT = 16, CHUNK = PERT * RK_I;
+    int carry = 0;
+    for (int base = 0; base < nb; base += CHUNK) {
+        int v[PERT];
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += o;
+        for (int k = 0; k < PERT; ++k) {
+            const int q = base + k * RK_I + tid;
+            v[k] = q < nb ? __hip_atomic_load(cnt + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < PERT; ++k) stile[k * RK_I + tid] = v[k];
+        __syncthreads();
+        int total = 0;
+#pragma unroll
+        for (int k = 0; k < PERT; ++k) { v[k] = stile[tid * PERT + k]; total += v[k]; }
+        int inc = total;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int pre = carry + inc - total, all = 0;
+        for (int w = 0; w < RK_I / 64; ++w) { if (w < wave) pre += wsum[w]; all += wsum[w]; }
+#pragma unroll
+        for (int k = 0; k < PERT; ++k) {
+            const int q = base + tid * PERT + k;
+            if (q < nb) off[q] = pre;
+            pre += v[k];
+        }
+        carry += all;
+        __syncthreads();
     }
-    if (lane == 63) wsum[wave] = inc;
-    __syncthreads();
-    int pre = inc - total;
-    for (int w = 0; w < wave; ++w) pre += wsum[w];
-    for (int q = lo; q < hi; ++q) { off[q] = pre; pre += __hip_atomic_load(cnt + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    if (tid == RK_I - 1) off[nb] = pre;
+    if (tid == 0) off[nb] = carry;
 }
 
 // one wave per output row.  rows [0, na - r): unmerged a-tokens in rank order; rows [na - r, n - r): b-tokens.
