@@ -204,7 +204,7 @@ int sttm_quadtree_merge_batch(int n_videos, const void* const* x, int64_t stride
  *   "fold_labels" 1: run a column's label stage inside the pair kernel, in the column's last workgroup to finish (default 0:
  *                 stand-alone label kernel; the folded form is no faster on MI355X and is kept for experiments)
  *   "pairs_var"   9: the general pair kernel instead of the lean 256-thread form (tests / A-B)
- *   "k1_var"      development build only (A/B): 1 = 3-level trees run the general spatial body (the one deeper trees use)
+ *   "k1_var"      development build only (A/B): 1 = 3- and 4-level trees run the general spatial body (the one deeper trees use)
  *   "no_dense"    1: column label stage always on compact ids (default: columns of <= 4096 slots work on their slots directly);
  *                 2: the round-3 form of the slot-indexed stage (three barriers per iteration; A/B)
  *   "no_fuse"     1: stand-alone label stage as two launches (no in-kernel grid barrier)

@@ -301,7 +301,9 @@ __device__ __forceinline__ void publish_counts(const TemporalArgs& a, int n_out,
 //        themselves.  The bitmask only says which slots take part (results are written for those); the prefix over the bit
 //        counts, the id table and the raw-pair staging with its conversion pass are gone (round 3: 1.8 of the label kernel's
 //        12 us went into the compaction of ~500 ids that fit LDS uncompacted).  Slots without a node keep label == slot.
-constexpr int kDenseSlots = 4096;
+constexpr int kDenseSlots = 3072;       // (round 4, same-box A/B: slot-indexed better at 2048 / 2880 slots -- 17.1 vs 18.0, 19.6 vs 20.8 us --,
+                                        //  compact ids better from 4096 on: 21.3 vs 21.5 us at T=256, 28.1 vs 30.4 us on the 20 x 36 grids,
+                                        //  whose 4096-slot edge columns were the slowest of the launch in the slot-indexed form)
 template <bool GMEM, int MODE, bool DENSE = false>
 __device__ __forceinline__ bool column_labels(const TemporalArgs& a, int r, const Column& col, const ColArrays& arr, ColShared* sh) {
     static_assert(!(GMEM && DENSE), "the dense form lives in LDS");
@@ -331,6 +333,7 @@ __device__ __forceinline__ bool column_labels(const TemporalArgs& a, int r, cons
         const int32_t* ecnt = a.edge_cnt + (int64_t)r * nf;
         for (int w = tid; w < W; w += nt) cst<GMEM>(bits + w, 0);
         if (tid == 0) sh->ecount = 0;
+        if (tid < 64) { sh->ch[tid] = 0; sh->bd[tid] = 0; }
         col_sync<GMEM>();
         auto take = [&](int t, int packed, int pos) {
             const unsigned w = (unsigned)packed;
@@ -439,6 +442,48 @@ __device__ __forceinline__ bool column_labels(const TemporalArgs& a, int r, cons
         unsigned long long mask = 0ull;
         int it = 0;
         bool overflow = false;
+        bool two_barrier = false;
+        if constexpr (!GMEM && !DENSE) two_barrier = 2 * nact <= arr.cap && E > 0;      // uniform: room for a third label array
+        if (two_barrier) {
+            // the dense form's two-barrier iteration (column_labels_dense) on compact ids: the next scatter target lives in the upper
+            // half of rep2 (the active nodes of a column that takes this path are a fraction of its slots), the idempotency check of
+            // iteration k rides in the edge pass of iteration k + 1, the copy pass is gone
+            int* Sc = rep2; int* Sn = rep2 + arr.cap / 2;
+            while (true) {
+                for (int e = tid; e < E; e += nt) {
+                    int d, s2;
+                    edge_get<false>(edges, e, d, s2);
+                    const int rd = rep[d], rs = rep[s2];
+                    const int m = rd < rs ? rd : rs;
+                    atomicMin(Sc + d, m);
+                    atomicMin(Sc + s2, m);
+                }
+                if (it > 0) {
+                    int bad = 0;
+                    for (int i = tid; i < nact; i += nt) {
+                        const int v = rep[i];
+                        if (rep[v] != v) bad = 1;
+                    }
+                    if (bad) sh->bd[it - 1] = 1;
+                }
+                lds_barrier();
+                int changed = 0;
+                for (int i = tid; i < nact; i += nt) {
+                    const int v = Sc[Sc[i]];
+                    if (v != rep[i]) changed = 1;
+                    rep[i] = v;
+                    Sn[i] = v;
+                }
+                if (changed) sh->ch[it] = 1;
+                lds_barrier();
+                if (it > 0 && !sh->bd[it - 1]) mask |= 1ull << (it - 1);
+                const int chg = sh->ch[it];
+                ++it;
+                int* tmp = Sc; Sc = Sn; Sn = tmp;
+                if (!chg) break;
+                if (it >= kMaxProbeIters) { overflow = true; break; }
+            }
+        } else
         while (true) {
             // alternate flag pairs: iteration k+1 resets the OTHER pair, so no barrier is needed between reading this
             // iteration's flags and starting the next one (the pair is reused two iterations, i.e. >= 3 barriers, later)

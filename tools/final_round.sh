@@ -5,9 +5,10 @@
 set -u
 TAG=${1:-r03z}
 mkdir -p gpurun_out
+# the PMC passes come first: they write profiles/pmc_traffic.json for THIS build tag, which the bench lines then carry as roofline.traffic
+bash tools/pmc_passes.sh ${TAG} > /dev/null 2>&1
 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 bash tools/profile_bench.sh ${TAG}_prof --steps 2 --warmup 1 --videos-per-step 512 --profile-calls 8
-bash tools/pmc_passes.sh ${TAG} > /dev/null 2>&1
 B="bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extensions --no-configs --profile-calls 64"
 python $B > gpurun_out/${TAG}_plain.json 2>/dev/null
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29641 $B --gpus 1 > gpurun_out/${TAG}_torchrun.json 2>/dev/null
