@@ -24,7 +24,7 @@ int fail(int code, const char* fmt, ...) {
 // Tuning / test switches: defaults from STTM_<KEY> environment variables, read ONCE; sttm_configure overrides them.
 // None of them changes results.
 struct Config {
-    int pairs_seg, pairs_nt, pairs_var, k1_var, no_dense, gm_split, label_nt, vec16, vec32, fold_kb, fold_labels, no_fuse, force_gmem_labels, tome_split, tome_flat, tome_rank;
+    int pairs_seg, pairs_nt, pairs_var, k1_var, k1_split, no_dense, gm_split, label_nt, vec16, vec32, fold_kb, fold_labels, no_fuse, force_gmem_labels, tome_split, tome_flat, tome_rank;
 };
 int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
@@ -37,6 +37,7 @@ Config& config() {
         d.pairs_nt = env_int("STTM_PAIRS_NT", 0);
         d.pairs_var = env_int("STTM_PAIRS_VAR", 0);
         d.k1_var = env_int("STTM_K1_VAR", 0);
+        d.k1_split = env_int("STTM_K1_SPLIT", 0);
         d.no_dense = env_int("STTM_NO_DENSE", 0);
         d.gm_split = env_int("STTM_GM_SPLIT", 0);
         d.label_nt = env_int("STTM_LABEL_NT", 1024);
@@ -138,6 +139,8 @@ struct Buffers {
     char* S; uint32_t* meta; double* inrm; int* rc_list;
     int32_t *edges; float* edge_sim; int32_t *edge_cnt, *cand_cnt; unsigned long long* col_mask; int32_t *col_arrive, *frame_cnt, *bar, *colscratch;
     int32_t *lab_row, *gcnt; uint32_t* cgeo;
+    char* tops;               // trees of 4 and more levels, the split spatial stage: [T][blocks][C] pooled tops of the 3-level blocks,
+                              // then [T * R][upper nodes][C] pooled features of the cells above them
 };
 
 size_t carve_all(const Plan& p, int T, int H, int W, int C, int dtype, char* base, Buffers* b) {
@@ -162,6 +165,7 @@ size_t carve_all(const Plan& p, int T, int H, int W, int C, int dtype, char* bas
     o.lab_row = c.take<int32_t>(N * 4);
     o.gcnt = c.take<int32_t>(N * 4);
     o.cgeo = c.take<uint32_t>((size_t)H * W * 4);
+    o.tops = c.take<char>(sttm::split_tops_bytes(T, p.dims, C, elem_bytes(dtype)) + sttm::split_ufeat_bytes(T, p.dims, C, elem_bytes(dtype)));
     return c.off;
 }
 
@@ -356,11 +360,6 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
     if (int rc = check_frame_addressing(H, W, C, (int)elem_bytes(dtype), stride_h, stride_w, stride_t)) return rc;
     const int vec = pick_vec(C, dtype, x_align, stride_t, stride_h, stride_w, &nt, head_dim == 0);
     if (!vec) return fail(STTM_ERR_UNSUPPORTED, "C=%d with this alignment does not fit one workgroup (need C/vec <= 1024 lanes)", C);
-    // a 6-level tree keeps 2735 partial statistics per wave in LDS (10.7 KB): at most 12 waves fit next to the other tables
-    if (p.dims.n_level >= 6 && nt > 768)
-        return fail(STTM_ERR_UNSUPPORTED, "a %d-level tree with %d lanes per token row does not fit the LDS (6-level trees: <= 768 lanes, "
-                    "i.e. fp32 C <= 3072, 16-bit C <= 6144)", p.dims.n_level, nt);
-
     int n_head = 0, head_lanes = 0;
     if (head_dim > 0) {
         // one head = head_dim / vec adjacent lanes: must be a power of two that fits a wave
@@ -440,7 +439,15 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
 
     hipError_t e;
     mark(events, 0, stream);
-    if ((e = sttm::launch_spatial(sa, bp, nv, dtype, vec, nt, stream)) != hipSuccess)
+    // trees of 4 and more levels (k1_split = -1: never; 5: from 5 levels): one workgroup per 3-level block + a pass over the upper levels
+    const int split_from = cfg.k1_split < 0 ? 99 : (cfg.k1_split == 5 ? 5 : 4);
+    void* tops = (n_head == 0 && p.dims.n_level >= split_from) ? b.tops : nullptr;
+    // the one-workgroup form of a 6-level tree (per-head cosine, k1_split = -1) keeps 2735 partial statistics per wave in LDS
+    // (10.7 KB): at most 12 waves fit next to the other tables
+    if (!tops && p.dims.n_level >= 6 && nt > 768)
+        return fail(STTM_ERR_UNSUPPORTED, "a %d-level tree with %d lanes per token row does not fit the LDS in the one-workgroup form "
+                    "(per-head cosine or k1_split = -1; 6-level trees: <= 768 lanes, i.e. fp32 C <= 3072, 16-bit C <= 6144)", p.dims.n_level, nt);
+    if ((e = sttm::launch_spatial(sa, bp, nv, dtype, vec, nt, stream, tops)) != hipSuccess)
         return fail(STTM_ERR_LAUNCH, "spatial kernel: %s", hipGetErrorString(e));
     mark(events, 1, stream);
 #ifdef STTM_DEV
@@ -494,7 +501,7 @@ int sttm_configure(const char* key, int value) {
     if (!key) return fail(STTM_ERR_ARG, "null key");
     Config& c = config();
     struct { const char* name; int* slot; } keys[] = {
-        {"pairs_seg", &c.pairs_seg}, {"pairs_nt", &c.pairs_nt}, {"pairs_var", &c.pairs_var}, {"k1_var", &c.k1_var}, {"no_dense", &c.no_dense}, {"gm_split", &c.gm_split}, {"label_nt", &c.label_nt},
+        {"pairs_seg", &c.pairs_seg}, {"pairs_nt", &c.pairs_nt}, {"pairs_var", &c.pairs_var}, {"k1_var", &c.k1_var}, {"k1_split", &c.k1_split}, {"no_dense", &c.no_dense}, {"gm_split", &c.gm_split}, {"label_nt", &c.label_nt},
         {"vec16", &c.vec16}, {"vec32", &c.vec32}, {"fold_kb", &c.fold_kb}, {"fold_labels", &c.fold_labels}, {"no_fuse", &c.no_fuse}, {"tome_split", &c.tome_split}, {"tome_flat", &c.tome_flat}, {"tome_rank", &c.tome_rank},
         {"force_gmem_labels", &c.force_gmem_labels},
     };

@@ -5,13 +5,13 @@
 namespace sttm {
 
 template <typename T, bool PERHEAD>
-hipError_t launch_spatial_t(const SpatialArgs& a, const BatchPtrs& bp, int n_videos, int vec, int nt, hipStream_t stream);
+hipError_t launch_spatial_t(const SpatialArgs& a, const BatchPtrs& bp, int n_videos, int vec, int nt, hipStream_t stream, void* tops);
 
-hipError_t launch_spatial(const SpatialArgs& a, const BatchPtrs& bp, int n_videos, int dtype, int vec, int nt, hipStream_t stream) {
+hipError_t launch_spatial(const SpatialArgs& a, const BatchPtrs& bp, int n_videos, int dtype, int vec, int nt, hipStream_t stream, void* tops) {
     const bool ph = a.n_head > 0;
-    if (dtype == STTM_F32) return ph ? launch_spatial_t<float, true>(a, bp, n_videos, vec, nt, stream) : launch_spatial_t<float, false>(a, bp, n_videos, vec, nt, stream);
-    if (dtype == STTM_BF16) return ph ? launch_spatial_t<bf16_t, true>(a, bp, n_videos, vec, nt, stream) : launch_spatial_t<bf16_t, false>(a, bp, n_videos, vec, nt, stream);
-    if (dtype == STTM_F16) return ph ? launch_spatial_t<f16_t, true>(a, bp, n_videos, vec, nt, stream) : launch_spatial_t<f16_t, false>(a, bp, n_videos, vec, nt, stream);
+    if (dtype == STTM_F32) return ph ? launch_spatial_t<float, true>(a, bp, n_videos, vec, nt, stream, tops) : launch_spatial_t<float, false>(a, bp, n_videos, vec, nt, stream, tops);
+    if (dtype == STTM_BF16) return ph ? launch_spatial_t<bf16_t, true>(a, bp, n_videos, vec, nt, stream, tops) : launch_spatial_t<bf16_t, false>(a, bp, n_videos, vec, nt, stream, tops);
+    if (dtype == STTM_F16) return ph ? launch_spatial_t<f16_t, true>(a, bp, n_videos, vec, nt, stream, tops) : launch_spatial_t<f16_t, false>(a, bp, n_videos, vec, nt, stream, tops);
     return hipErrorInvalidValue;
 }
 

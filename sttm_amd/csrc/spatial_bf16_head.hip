@@ -2,5 +2,5 @@
 #include "quadtree_spatial.inc"
 
 namespace sttm {
-template hipError_t launch_spatial_t<bf16_t, true>(const SpatialArgs&, const BatchPtrs&, int, int, int, hipStream_t);
+template hipError_t launch_spatial_t<bf16_t, true>(const SpatialArgs&, const BatchPtrs&, int, int, int, hipStream_t, void*);
 }  // namespace sttm

@@ -76,7 +76,20 @@ __device__ __forceinline__ void rebase(SpatialArgs& a, const BatchPtrs& bp, int 
     shift_ptr(a.gcnt, off); shift_ptr(a.frame_cnt, off); shift_ptr(a.bar, off); shift_ptr(a.col_arrive, off); shift_ptr(a.cgeo, off);
     a.counts += (size_t)v * STTM_CNT_SLOTS;
 }
-hipError_t launch_spatial(const SpatialArgs& a, const BatchPtrs& bp, int n_videos, int dtype, int vec, int nt, hipStream_t stream);
+// bytes of the block-top table of the split spatial stage (256-byte multiple; the upper-cell feature table follows it)
+inline size_t split_tops_bytes(int T, const LevelDims& d, int C, int elem_bytes) {
+    const int ul = d.n_level - 3;
+    if (ul < 1) return 0;
+    return ((size_t)T * d.h[ul] * d.w[ul] * C * elem_bytes + 255) / 256 * 256;
+}
+inline size_t split_ufeat_bytes(int T, const LevelDims& d, int C, int elem_bytes) {
+    const int ul = d.n_level - 3;
+    if (ul < 1) return 0;
+    return (size_t)T * d.h[0] * d.w[0] * depth_base(ul) * C * elem_bytes;
+}
+// tops != null: trees of 4 and more levels run in the split form (one workgroup per 3-level block + a pass over the upper levels;
+// whole-vector cosine only); tops = [T][h_block_level][w_block_level][C] elements of the input dtype per video, inside the workspace
+hipError_t launch_spatial(const SpatialArgs& a, const BatchPtrs& bp, int n_videos, int dtype, int vec, int nt, hipStream_t stream, void* tops = nullptr);
 hipError_t launch_node_apply(const SpatialArgs& a, int dtype, int vec, int nt, hipStream_t stream);
 
 struct TemporalArgs {

@@ -139,17 +139,70 @@ def test_against_oracle(case):
 
 
 def test_six_level_tree_row_width_limit():
-    """6-level trees keep 10.7 KB of partial statistics per wave in LDS: rows of up to 768 lanes (12 waves) work, wider ones are
-    refused loudly (NotImplementedError), never launched."""
+    """The split spatial stage (one workgroup per 3-level block + a pass over the upper levels) has no row-width limit of its own:
+    a 6-level tree over 4096-channel fp32 rows (1024 lanes) runs and matches the oracle.  The one-workgroup form (k1_split = -1;
+    per-head cosine) keeps 10.7 KB of partial statistics per wave in LDS: rows of up to 768 lanes (12 waves) work there, wider ones
+    are refused loudly (NotImplementedError), never launched."""
     from oracle import sttm_oracle as O
-    from sttm_amd import get_quadtree_features
+    from sttm_amd import _lib, get_quadtree_features
     from sttm_amd.synth import synth_video
     x = synth_video(1, 3072, 36, 40, seed=95)                  # 768 lanes of 4 floats
     exp = O.get_quadtree_features(x, 0.85, -1.0, 0, False)
-    out = get_quadtree_features(x.to(_dev()), 0.85, -1.0, 0, False)
-    _check(out, exp, FP32_TOL, "6 levels, 768 lanes")
-    with pytest.raises(NotImplementedError, match="LDS"):
-        get_quadtree_features(synth_video(1, 4096, 36, 40, seed=96).to(_dev()), 0.85, -1.0, 0, False)
+    xw = synth_video(1, 4096, 36, 40, seed=96)
+    expw = O.get_quadtree_features(xw, 0.85, -1.0, 0, False)
+    _check(get_quadtree_features(xw.to(_dev()), 0.85, -1.0, 0, False), expw, FP32_TOL, "6 levels, 1024 lanes, split form")
+    try:
+        _lib.configure(k1_split=-1)
+        out = get_quadtree_features(x.to(_dev()), 0.85, -1.0, 0, False)
+        _check(out, exp, FP32_TOL, "6 levels, 768 lanes")
+        with pytest.raises(NotImplementedError, match="LDS"):
+            get_quadtree_features(xw.to(_dev()), 0.85, -1.0, 0, False)
+    finally:
+        _lib.configure(k1_split=0)
+
+
+DEEP_CASES = [
+    # (T, C, H, W, seed, dtype, threshold, temporal, root_level, synth kwargs)
+    (6, 1024, 20, 36, 4, torch.float32, 0.85, 0.60, 1, {}),                        # 4 levels (BASELINE config 4 grid)
+    (5, 512, 27, 27, 8, torch.float32, 0.80, 0.50, 0, {}),                         # 5 levels
+    (3, 256, 36, 64, 36, torch.float32, 0.85, 0.55, 0, {}),                        # 6 levels
+    (2, 1024, 33, 47, 39, torch.float32, 0.75, 0.50, 0, {}),                       # odd sides at several levels (alias cells)
+    (3, 128, 40, 40, 37, torch.bfloat16, 0.80, 0.50, 0, {}),
+    (4, 256, 36, 64, 50, torch.float32, 0.70, 0.50, 0, dict(c=0.05, p_static=0.9)),    # smooth: nodes at every upper level
+    (4, 192, 35, 61, 51, torch.float16, 0.60, 0.50, 0, dict(c=0.05, p_static=0.9)),
+    (3, 2048, 36, 64, 40, torch.float16, 0.85, 0.55, 1, {}),                       # 32-byte packs, 5 levels
+]
+
+
+@pytest.mark.parametrize("case", DEEP_CASES, ids=lambda c: "T%d_C%d_%dx%d_s%d_r%d" % (c[:5] + (c[8],)))
+def test_deep_tree_split_and_one_workgroup_forms_agree(case):
+    """Trees of 4 and more levels run as one workgroup per 3-level block + a pass over the upper levels (default) or as one workgroup
+    per root cell (k1_split = -1: the general body / the 4-level one-shape body): both against the oracle, and bit-identical to each
+    other -- also through the batched entry point, where every video has its own block-top table."""
+    from oracle import sttm_oracle as O
+    from sttm_amd import _lib, get_quadtree_features
+    from sttm_amd.quadtree_interface import get_quadtree_features_batch
+    from sttm_amd.synth import synth_video
+    T, C, H, W, seed, dtype, thr, tthr, root, kw = case
+    xs = [synth_video(T, C, H, W, seed=seed + 100 * i, dtype=dtype, **kw) for i in range(3)]
+    exp = O.get_quadtree_features(xs[0], thr, tthr, root, False)
+    tol = FP32_TOL if dtype == torch.float32 else BF16_TOL
+    xd = [x.to(_dev()) for x in xs]
+    outs = {}
+    try:
+        for mode in (0, -1):
+            _lib.configure(k1_split=mode)
+            outs[mode] = [get_quadtree_features(x, thr, tthr, root, False) for x in xd]
+            _check(outs[mode][0], exp, tol, f"k1_split={mode}")
+        _lib.configure(k1_split=0)
+        batch = get_quadtree_features_batch(xd, thr, tthr, root, False)
+    finally:
+        _lib.configure(k1_split=0)
+    if len(case[9]):
+        assert int((exp[1] > 16).sum()) > 0, "the smooth case should contain nodes above the block level"
+    for a, b, c in zip(outs[0], outs[-1], batch):
+        for u, v, w in zip(a, b, c):
+            assert torch.equal(u, v) and torch.equal(u, w)
 
 
 @pytest.mark.parametrize("pe_weighted", [False, True])

@@ -24,6 +24,10 @@ NO_SCRATCH = [
     ("K1 bf16 C<=2048", r"k_spatialINS_6bf16_tELi8ELi3ELi0ELi256ELb0E"),
     ("K1 fp16 C<=2048", r"k_spatialINS_5f16_tELi8ELi3ELi0ELi256ELb0E"),
     ("K1 C4 grids (20x36, 18x26): fp32 4-level tree", r"k_spatialIfLi4ELi3ELi1ELi256ELb0E"),
+    ("K1 split form, pass A (trees of 4+ levels: one workgroup per 3-level block), fp32", r"k_spatial_blocksIfLi4ELi256E"),
+    ("K1 split form, pass A, bf16 32-byte packs", r"k_spatial_blocksINS_6bf16_tELi16ELi256E"),
+    ("K1 split form, pass B over one upper level (C4 grids)", r"k_spatial_upperIfLi4ELi1ELi256E"),
+    ("K1 split form, pass B over three upper levels (6-level trees)", r"k_spatial_upperIfLi4ELi3ELi256E"),
     ("K2 fp32 (8-wide row packs)", r"k_pairs256IfLi8ELi5ELi32E"),
     ("K2 bf16", r"k_pairs256INS_6bf16_tELi8ELi5ELi64E"),
     ("K3 fused label stage", r"k_col_labelsILi2E"),

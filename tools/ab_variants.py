@@ -20,6 +20,11 @@ SHAPES = {
     "t256": (256, 1024, 14, 14, torch.float32, 0.85, 0.55),
     "wide": (128, 8192, 14, 14, torch.bfloat16, 0.85, 0.55),
     "bf16n": (128, 2048, 14, 14, torch.bfloat16, 0.85, 0.55),
+    # deep trees (an 8th entry = root_level): 36 x 64 tokens at root_level 0 / 1 = 6- / 5-level trees, 27 x 27 at 0 = 5 levels
+    "deep6": (16, 1024, 36, 64, torch.float32, 0.85, 0.55, 0),
+    "deep5": (16, 1024, 36, 64, torch.float32, 0.85, 0.55, 1),
+    "deep5b": (64, 1024, 27, 27, torch.float32, 0.85, 0.55, 0),
+    "deep6h": (16, 3584, 36, 64, torch.bfloat16, 0.85, 0.55, 0),
 }
 KEYS_RESET = {}
 
@@ -45,24 +50,25 @@ def main():
         args = args[2:]
     specs = args or ["default"]
     for sh in shapes:
-        T, C, H, W, dt, thr, tthr = SHAPES[sh]
+        T, C, H, W, dt, thr, tthr = SHAPES[sh][:7]
+        RL = SHAPES[sh][7] if len(SHAPES[sh]) > 7 else 1
         P = 8 if sh not in ("c4", "c4b", "wide", "t256") else 4
         pool = [synth_video(T, C, H, W, seed=i, dtype=dt, device=dev, gen_device=dev) for i in range(P)]
         configure("default")
-        ref = [get_quadtree_features(x, thr, tthr, 1) for x in pool]
+        ref = [get_quadtree_features(x, thr, tthr, RL) for x in pool]
         torch.cuda.synchronize()
         print(f"== {sh}: T={T} C={C} {H}x{W} {dt} ==", flush=True)
         for spec in specs:
             configure(spec)
             same = True
             for x, r in zip(pool, ref):
-                f, n, t = get_quadtree_features(x, thr, tthr, 1)
+                f, n, t = get_quadtree_features(x, thr, tthr, RL)
                 same &= bool(torch.equal(f, r[0]) and torch.equal(n, r[1]) and torch.equal(t, r[2]))
             ev = _lib.KernelEvents()
             tot = [0.0] * 4
             calls = 256
             for i in range(calls):
-                quadtree_merge_raw(pool[i % P], thr, tthr, 1, False, None, events=ev, return_ctx=True)
+                quadtree_merge_raw(pool[i % P], thr, tthr, RL, False, None, events=ev, return_ctx=True)
                 ms = ev.elapsed_ms()
                 for k in range(4):
                     tot[k] += ms[k]
@@ -72,7 +78,7 @@ def main():
                 t0 = time.perf_counter()
                 n_it = 1024
                 for i in range(n_it):
-                    get_quadtree_features(pool[i % P], thr, tthr, 1)
+                    get_quadtree_features(pool[i % P], thr, tthr, RL)
                 torch.cuda.synchronize()
                 best = min(best, (time.perf_counter() - t0) / n_it)
             print(f"{spec:40s} identical={same}  K1 {tot[0] / calls * 1e3:6.2f}  K2 {tot[1] / calls * 1e3:6.2f}  K3 {tot[2] / calls * 1e3:6.2f}  "

@@ -15,9 +15,10 @@ lib.sttm_dev_hooks.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctyp
 dev = torch.device("cuda:0")
 T, C, H, W = int(os.environ.get("T", "128")), 1024, int(os.environ.get("H", "14")), int(os.environ.get("W", "14"))
 THR, TTHR = float(os.environ.get("THR", "0.85")), float(os.environ.get("TTHR", "0.55"))
+RL = int(os.environ.get("RL", "1"))          # root_level (36 x 64 tokens at RL=0: a 6-level tree, the split spatial stage)
 k1_wg, k2_wg, col = (int(a) for a in (sys.argv[1:4] + ["0", "0", "0"])[:3])
 x = synth_video(T, C, H, W, seed=1, device=dev, gen_device=dev)
-nbytes = lib.sttm_quadtree_workspace_bytes(T, H, W, C, 0, 1)
+nbytes = lib.sttm_quadtree_workspace_bytes(T, H, W, C, 0, RL)
 ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
 N = T * H * W
 feat = torch.empty((N, C), device=dev); npatch = torch.empty(N, dtype=torch.int32, device=dev)
@@ -25,6 +26,7 @@ tlbr = torch.empty((N, 5), dtype=torch.int32, device=dev); counts = torch.zeros(
 ticks = torch.zeros(48, dtype=torch.int64, device=dev)
 lib.sttm_dev_hooks(0, ticks.data_ptr(), k1_wg, k2_wg, col)
 names = {0: ("spatial workgroup", ["start", "loads+pool", "stats", "decide+emit", "stores"]),
+         8: ("upper pass of the split spatial stage (trees of 4+ levels)", ["start", "prefetch+clear+aliases", "statistics", "tests", "emission walk", "stores"]),
          16: ("pair workgroup", ["start", "lists+box tests", "dots", "published"]),
          32: ("label stage", ["start", "edges+bits", "compact ids", "probe", "grid barrier", "K+replay", "sizes+results", "frame counts", "arrival"])}
 acc = {k: None for k in names}
@@ -32,7 +34,7 @@ runs = 0
 for it in range(12):
     ticks.zero_()
     rc = lib.sttm_quadtree_merge(x.data_ptr(), x.stride(0), x.stride(1), x.stride(2), x.stride(3), T, C, H, W, 0,
-                                 THR, TTHR, 1, 0, 0, 0, ws.data_ptr(), nbytes, feat.data_ptr(), npatch.data_ptr(),
+                                 THR, TTHR, RL, 0, 0, 0, ws.data_ptr(), nbytes, feat.data_ptr(), npatch.data_ptr(),
                                  tlbr.data_ptr(), counts.data_ptr(), torch.cuda.current_stream().cuda_stream)
     assert rc == 0, _lib.last_error()
     torch.cuda.synchronize()
