@@ -205,7 +205,10 @@ int sttm_quadtree_merge_batch(int n_videos, const void* const* x, int64_t stride
  *                 stand-alone label kernel; the folded form is no faster on MI355X and is kept for experiments)
  *   "pairs_var"   9: the general pair kernel instead of the lean 256-thread form (tests / A-B)
  *   "k1_var"      development build only (A/B): 1 = 3- and 4-level trees run the general spatial body (the one deeper trees use)
- *   "no_dense"    1: column label stage always on compact ids (default: columns of <= 4096 slots work on their slots directly);
+ *   "k1_split"    spatial stage of trees with 4 and more levels: 0 (default) one workgroup per 3-level block + a pass over the upper
+ *                 levels (two launches; whole-vector cosine); -1 = one workgroup per root cell (the form the per-head cosine always
+ *                 uses; 6-level trees then need <= 768 lanes per token row); 5 = the split form from 5 levels on.  Same outputs.
+ *   "no_dense"    1: column label stage always on compact ids (default: columns of <= 3072 slots work on their slots directly);
  *                 2: the round-3 form of the slot-indexed stage (three barriers per iteration; A/B)
  *   "no_fuse"     1: stand-alone label stage as two launches (no in-kernel grid barrier)
  *   "force_gmem_labels"  1: label stage on global scratch instead of LDS (the path of columns too large for LDS)

@@ -1,5 +1,6 @@
 """Seeded fuzz of the HIP path against the oracle over random shapes / thresholds / variants (small sizes).
-STTM_FUZZ_N / STTM_FUZZ_SEED / STTM_FUZZ_TMAX widen or move the sweep for one-off runs (defaults: 200 cases, seed 1234)."""
+STTM_FUZZ_N / STTM_FUZZ_SEED / STTM_FUZZ_TMAX / STTM_FUZZ_HMAX / STTM_FUZZ_WMAX widen or move the sweep for one-off runs (defaults: 200
+cases, seed 1234, grids up to 30 x 40; 70 x 70 reaches the 6-level trees of the split spatial stage)."""
 import os
 import random
 
@@ -13,7 +14,7 @@ def _cases(n, seed):
     rng = random.Random(seed)
     out = []
     while len(out) < n:
-        H, W = rng.randint(3, 30), rng.randint(3, 40)
+        H, W = rng.randint(3, int(os.environ.get("STTM_FUZZ_HMAX", "30"))), rng.randint(3, int(os.environ.get("STTM_FUZZ_WMAX", "40")))
         T = rng.randint(1, int(os.environ.get("STTM_FUZZ_TMAX", "7")))
         C = rng.choice([8, 12, 16, 20, 32, 64, 100, 128, 256])
         dtype = rng.choice([torch.float32, torch.float32, torch.bfloat16, torch.float16])

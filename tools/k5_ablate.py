@@ -8,13 +8,15 @@ from sttm_amd.quadtree_interface import quadtree_merge_raw
 from sttm_amd.synth import synth_video
 lib = _lib.load()
 dev = torch.device("cuda:0")
-pool = [synth_video(128, 1024, 14, 14, seed=i, device=dev, gen_device=dev) for i in range(8)]
+T, H, W = int(os.environ.get("T", "128")), int(os.environ.get("H", "14")), int(os.environ.get("W", "14"))
+THR, TTHR, RL = float(os.environ.get("THR", "0.85")), float(os.environ.get("TTHR", "0.55")), int(os.environ.get("RL", "1"))
+pool = [synth_video(T, 1024, H, W, seed=i, device=dev, gen_device=dev) for i in range(8 if H * W < 400 else 4)]
 ev = _lib.KernelEvents()
 for mode in (0, 1, 0, 1):
     lib.sttm_dev_k5_mode(mode)
     tot = [0.0] * 4; n = 0
     for it in range(48):
-        quadtree_merge_raw(pool[it % 8], 0.85, 0.55, 1, False, None, events=ev)
+        quadtree_merge_raw(pool[it % len(pool)], THR, TTHR, RL, False, None, events=ev)
         ms = ev.elapsed_ms()
         if it >= 8:
             tot = [a + b for a, b in zip(tot, ms)]; n += 1
