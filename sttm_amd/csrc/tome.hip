@@ -977,6 +977,9 @@ template <typename T, int VEC> __device__ __forceinline__ void tome_st_vec(void*
     }
 }
 // VEC channels per lane and step (VEC * sizeof(T) bytes per access); the per-element arithmetic does not depend on VEC.
+// Round 4: 16-byte accesses for every dtype (16-bit rows: 8 channels per lane), up to NCH row chunks of a token in flight per lane
+// (C = 1024: the whole row), and a destination's sources looked up ONCE by the lanes in parallel (rank -> token -> size) instead
+// of two dependent loads per source and chunk -- the old form moved T = 128 in 28-38 us = 2.3-3 TB/s.
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256) k_tome_merge(const void* __restrict__ x, const float* __restrict__ size,
                                                     const int64_t* __restrict__ idx, int n, int C, int na, int nb, int r,
@@ -987,16 +990,27 @@ __global__ void __launch_bounds__(256) k_tome_merge(const void* __restrict__ x, 
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     const int n_out = n - r;
+    constexpr int NCH = VEC >= 8 ? 2 : 4;   // chunks of 64 * VEC channels handled together (fp32 / 16-bit C = 1024: the whole row)
     for (int row = blockIdx.x * nwave + wave; row < n_out; row += gridDim.x * nwave) {
         if (row < na - r) {
             const int tok = 2 * order[r + row];                   // unmerged a-token: (x*size)/size
             const float s = size ? size[tok] : 1.f;
-            for (int c = lane * VEC; c < C; c += 64 * VEC) {
-                float v[VEC];
-                tome_ld_vec<T, VEC>(x, (int64_t)tok * C + c, v);
+            for (int c0 = 0; c0 < C; c0 += NCH * 64 * VEC) {
+                float v[NCH][VEC];
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) v[e] = tome_round<T>(v[e] * s) / s;
-                tome_st_vec<T, VEC>(x_out, (int64_t)row * C + c, v);
+                for (int u = 0; u < NCH; ++u) {
+                    const int c = c0 + (u * 64 + lane) * VEC;
+                    if (c < C) tome_ld_vec<T, VEC>(x, (int64_t)tok * C + c, v[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < NCH; ++u) {
+                    const int c = c0 + (u * 64 + lane) * VEC;
+                    if (c < C) {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) v[u][e] = tome_round<T>(v[u][e] * s) / s;
+                        tome_st_vec<T, VEC>(x_out, (int64_t)row * C + c, v[u]);
+                    }
+                }
             }
             if (lane == 0) { size_out[row] = s; idx_out[row] = idx[tok]; }
             continue;
@@ -1034,26 +1048,76 @@ __global__ void __launch_bounds__(256) k_tome_merge(const void* __restrict__ x, 
         // The products x * size are tensors of their own and are rounded individually (both routes agree on that).
         const float sb = size ? size[tok] : 1.f;
         float stot = sb;
-        for (int m = 0; m < cnt; ++m) {
-            const int atok = 2 * order[lists[o + m]];
-            stot = stot + (size ? size[atok] : 1.f);
-        }
-        stot = tome_round<T>(stot);
-        for (int c = lane * VEC; c < C; c += 64 * VEC) {
-            float acc[VEC], xa[VEC];
-            tome_ld_vec<T, VEC>(x, (int64_t)tok * C + c, acc);
+        if (cnt <= 64) {
+            // lane m holds source m (ascending rank): its token and size, fetched by all lanes at once
+            int atok_l = 0;
+            float sa_l = 1.f;
+            if (lane < cnt) {
+                atok_l = 2 * order[lists[o + lane]];
+                sa_l = size ? size[atok_l] : 1.f;
+            }
+            for (int m = 0; m < cnt; ++m) stot = stot + __shfl(sa_l, m, 64);
+            stot = tome_round<T>(stot);
+            for (int c0 = 0; c0 < C; c0 += NCH * 64 * VEC) {
+                float acc[NCH][VEC], xa[NCH][VEC];
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) acc[e] = tome_round<T>(acc[e] * sb);      // plain operators: the __fmul_rn/__fadd_rn wrappers fuse once inlined
+                for (int u = 0; u < NCH; ++u) {
+                    const int c = c0 + (u * 64 + lane) * VEC;
+                    if (c < C) tome_ld_vec<T, VEC>(x, (int64_t)tok * C + c, acc[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < NCH; ++u)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[u][e] = tome_round<T>(acc[u][e] * sb);      // plain operators: the __fmul_rn/__fadd_rn wrappers fuse once inlined
+                for (int m = 0; m < cnt; ++m) {
+                    const int atok = __shfl(atok_l, m, 64);
+                    const float sa = __shfl(sa_l, m, 64);
+#pragma unroll
+                    for (int u = 0; u < NCH; ++u) {
+                        const int c = c0 + (u * 64 + lane) * VEC;
+                        if (c < C) tome_ld_vec<T, VEC>(x, (int64_t)atok * C + c, xa[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < NCH; ++u) {
+                        const int c = c0 + (u * 64 + lane) * VEC;
+                        if (c < C) {
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) acc[u][e] = acc[u][e] + tome_round<T>(xa[u][e] * sa);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < NCH; ++u) {
+                    const int c = c0 + (u * 64 + lane) * VEC;
+                    if (c < C) {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) acc[u][e] = tome_round<T>(acc[u][e]) / stot;
+                        tome_st_vec<T, VEC>(x_out, (int64_t)row * C + c, acc[u]);
+                    }
+                }
+            }
+        } else {
             for (int m = 0; m < cnt; ++m) {
                 const int atok = 2 * order[lists[o + m]];
-                const float sa = size ? size[atok] : 1.f;
-                tome_ld_vec<T, VEC>(x, (int64_t)atok * C + c, xa);
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) acc[e] = acc[e] + tome_round<T>(xa[e] * sa);
+                stot = stot + (size ? size[atok] : 1.f);
             }
+            stot = tome_round<T>(stot);
+            for (int c = lane * VEC; c < C; c += 64 * VEC) {
+                float acc[VEC], xa[VEC];
+                tome_ld_vec<T, VEC>(x, (int64_t)tok * C + c, acc);
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) acc[e] = tome_round<T>(acc[e]) / stot;
-            tome_st_vec<T, VEC>(x_out, (int64_t)row * C + c, acc);
+                for (int e = 0; e < VEC; ++e) acc[e] = tome_round<T>(acc[e] * sb);
+                for (int m = 0; m < cnt; ++m) {
+                    const int atok = 2 * order[lists[o + m]];
+                    const float sa = size ? size[atok] : 1.f;
+                    tome_ld_vec<T, VEC>(x, (int64_t)atok * C + c, xa);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[e] = acc[e] + tome_round<T>(xa[e] * sa);
+                }
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[e] = tome_round<T>(acc[e]) / stot;
+                tome_st_vec<T, VEC>(x_out, (int64_t)row * C + c, acc);
+            }
         }
         if (lane == 0) { size_out[row] = stot; idx_out[row] = idx[tok]; }
     }
@@ -1273,9 +1337,10 @@ int sttm_tome_step(const void* x_, const float* size, const int64_t* idx, int n,
 #define STTM_TOME_MERGE(TT, VV) hipLaunchKernelGGL((k_tome_merge<TT, VV>), dim3(grid), dim3(256), 0, stream, x_, size, idx, n, C, p.na, p.nb, r, order, off, lists, x_out_, size_out, idx_out)
         const size_t eb = dtype == STTM_F32 ? 4 : 2;
         const bool v4 = C % 4 == 0 && reinterpret_cast<uintptr_t>(x_) % (4 * eb) == 0 && reinterpret_cast<uintptr_t>(x_out_) % (4 * eb) == 0;
+        const bool v8 = C % 8 == 0 && reinterpret_cast<uintptr_t>(x_) % 16 == 0 && reinterpret_cast<uintptr_t>(x_out_) % 16 == 0;
         if (dtype == STTM_F32) { if (v4) STTM_TOME_MERGE(float, 4); else STTM_TOME_MERGE(float, 1); }
-        else if (dtype == STTM_BF16) { if (v4) STTM_TOME_MERGE(bf16_t, 4); else STTM_TOME_MERGE(bf16_t, 1); }
-        else { if (v4) STTM_TOME_MERGE(f16_t, 4); else STTM_TOME_MERGE(f16_t, 1); }
+        else if (dtype == STTM_BF16) { if (v8) STTM_TOME_MERGE(bf16_t, 8); else if (v4) STTM_TOME_MERGE(bf16_t, 4); else STTM_TOME_MERGE(bf16_t, 1); }
+        else { if (v8) STTM_TOME_MERGE(f16_t, 8); else if (v4) STTM_TOME_MERGE(f16_t, 4); else STTM_TOME_MERGE(f16_t, 1); }
 #undef STTM_TOME_MERGE
     }
     if (node_max_out) (void)hipMemcpyAsync(node_max_out, nmax, (size_t)p.na * 4, hipMemcpyDeviceToDevice, stream);
