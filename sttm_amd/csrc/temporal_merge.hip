@@ -1396,13 +1396,22 @@ __device__ __forceinline__ void store_pack_buf(__amdgpu_buffer_rsrc_t rs, uint32
 
 struct GmRow { int p, out, n; uint32_t mt, geo; };       // wave-uniform: slot in the frame, output row, group size, box, column geometry
 
-template <typename T, int VEC, int OCC, bool MEM2>
+constexpr int kGmLongN = 10;      // COOP: groups of more than this many members are handled by the whole workgroup, after its other rows
+constexpr int kGmQueue = 48;      // ... at most this many per workgroup (more: the plain path)
+
+template <typename T, int VEC, int OCC, bool MEM2, bool COOP>
 __global__ void __launch_bounds__(256, OCC) k_group_mean(const TemporalArgs a0, const BatchPtrs bp) {
     TemporalArgs a = a0;
     rebase(a, bp, blockIdx.y);
     constexpr int eb = TypeInfo<T>::bytes;
     const int lane = threadIdx.x & 63, nwave = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __shared__ GmRow lq[COOP ? kGmQueue : 1];
+    __shared__ int lqn;
+    if constexpr (COOP) {
+        if (threadIdx.x == 0) lqn = 0;
+        __syncthreads();
+    }
     const int S = a.gm_split, t = blockIdx.x / S, s = blockIdx.x - t * S;
     const int HW = a.H * a.W;
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.bar) {
@@ -1579,18 +1588,143 @@ __global__ void __launch_bounds__(256, OCC) k_group_mean(const TemporalArgs a0, 
         // metadata fetched by fewer waves -- was built in round 4 and measured slower in every configuration: headline 23.4 -> 24.8 us,
         // bf16 C=3584 40.4 -> 44.5 us; one row per wave and as many waves as possible stays)
         for (; jk < j0 + nchunk; jk += stride) {
+            const GmRow r = find(jk);
+            if constexpr (COOP) {
+                if (r.n > kGmLongN) {              // (uniform) a long group: queued for the whole workgroup
+                    int pos = 0;
+                    if (lane == 0) pos = atomicAdd(&lqn, 1);
+                    pos = __builtin_amdgcn_readfirstlane(pos);
+                    if (pos < kGmQueue) {
+                        if (lane == 0) lq[pos] = r;
+                        continue;
+                    }
+                }
+            }
             Pack<T, VEC> acc[U];
-            finish(find(jk), acc, false);
+            finish(r, acc, false);
         }
         j0 += nchunk;
+    }
+    if constexpr (COOP) {
+        // ---- long groups, all waves of the workgroup together ------------------------------------------------------------------
+        // A survivor's member rows are a chain of dependent loads in ascending order (the reference's accumulation order,
+        // quadtree_temporal_merger.py:123-145): with one wave per survivor a static region that lives through the clip -- 100+ members on
+        // the heavily merged 20 x 36 grids -- is 50+ round trips at the end of the kernel while the device drains.  The sums are
+        // independent per channel, so the waves split the CHANNELS of such a group (16 bytes per lane: a quarter of a fp32 C = 1024
+        // row per wave), every wave adds the members in the same ascending order, scans the column's labels eight chunks of 64
+        // slots per round trip and keeps up to eight member chunks in flight.
+        __syncthreads();
+        const int nq = lqn < kGmQueue ? lqn : kGmQueue;
+        constexpr int VC = 16 / eb;                // channels per lane
+        constexpr int NBS = 8, MB = 8;
+        const unsigned magicWc = a.W > 1 ? 0xffffffffu / (unsigned)a.W + 1u : 0u;
+        for (int qi = 0; qi < nq; ++qi) {
+            const GmRow r = lq[qi];
+            const int n = r.n;
+            const int y1 = a.W > 1 ? (int)__umulhi((unsigned)r.p, magicWc) : r.p, x1 = r.p - y1 * a.W;
+            const int y2 = (int)(r.mt >> 16), x2 = (int)(r.mt & 0xffff);
+            const int area = (y2 - y1) * (x2 - x1);
+            const int origin = t * HW + r.p;
+            const Column col = column_from_geo(a, r.geo);
+            const int slot0 = t * col.A + (y1 - col.Y1) * col.aw + (x1 - col.X1);
+            const void* s0 = (area == 1 && a.xrows) ? a.xrows : a.S;
+            int patches = area;
+            bool first_pass = true;
+            for (int cb0 = wave * 64 * VC; cb0 < a.C || first_pass; cb0 += nwave * 64 * VC) {
+                // (a wave without channels still walks the scan once: `patches` is wave 0's, but keeping the loop shape uniform is simpler)
+                const bool has_ch = cb0 < a.C;
+                if (!has_ch && !(first_pass && wave == 0)) break;
+                auto desc = [&](const void* basep, int row) {
+                    const int cb = has_ch ? cb0 : 0;
+                    const char* q = reinterpret_cast<const char*>(basep) + ((int64_t)row * a.C + cb) * eb;
+                    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(q), 0, has_ch ? (a.C - cb) * eb : 0, 0x00020000);
+                };
+                const uint32_t voff = (uint32_t)(lane * VC * eb);
+                Pack<T, VC> acc = load_pack_buf<T, VC>(desc(s0, origin), voff);
+                int found = 0, pend = 0;
+                int prow[MB], parea[MB];
+#pragma unroll
+                for (int k = 0; k < MB; ++k) { prow[k] = 0; parea[k] = 0; }
+                auto flush = [&]() {
+                    Pack<T, VC> qv[MB];
+#pragma unroll
+                    for (int k = 0; k < MB; ++k)
+                        if (k < pend) qv[k] = load_pack_buf<T, VC>(desc((parea[k] == 1 && a.xrows) ? a.xrows : a.S, prow[k]), voff);
+#pragma unroll
+                    for (int k = 0; k < MB; ++k)
+                        if (k < pend) {
+                            const Pack<T, VC> prev = acc;
+                            pack_fill(acc, [&](int e) { return prev.get(e) + qv[k].get(e); });
+                        }
+                    pend = 0;
+                };
+                for (int sb = slot0 + 1; found < n - 1 && sb < col.slots; sb += 64 * NBS) {
+                    int lbs[NBS], mrows[NBS];
+                    uint32_t qs[NBS];
+#pragma unroll
+                    for (int b = 0; b < NBS; ++b) {
+                        const int sl = sb + b * 64 + lane;
+                        const int slc = sl < col.slots ? sl : col.slots - 1;
+                        const int mr0 = slot_to_row(a, col, slc);
+                        lbs[b] = a.lab_row[mr0];
+                        qs[b] = a.meta[mr0];
+                        mrows[b] = sl < col.slots ? mr0 : -1;
+                    }
+#pragma unroll
+                    for (int b = 0; b < NBS; ++b) {
+                        const int sl = sb + b * 64 + lane;
+                        const bool hit = mrows[b] >= 0 && lbs[b] == origin;
+                        unsigned long long mm = __ballot(hit);
+                        if (mm == 0ull) continue;
+                        int ar = 0;
+                        if (hit) {
+                            const int rem = mrows[b] - slot_frame(col, sl) * HW;
+                            const int my1 = a.W > 1 ? (int)__umulhi((unsigned)rem, magicWc) : rem, mx1 = rem - my1 * a.W;
+                            ar = ((int)(qs[b] >> 16) - my1) * ((int)(qs[b] & 0xffff) - mx1);
+                        }
+                        while (mm) {
+                            const int k0 = __ffsll((long long)mm) - 1;
+                            mm &= mm - 1ull;
+                            const int mr = __builtin_amdgcn_readlane(mrows[b], k0), ak = __builtin_amdgcn_readlane(ar, k0);
+#pragma unroll
+                            for (int k = 0; k < MB; ++k)
+                                if (k == pend) { prow[k] = mr; parea[k] = ak; }
+                            ++pend; ++found;
+                            if (first_pass) patches += ak;
+                            if (pend == MB) flush();
+                        }
+                    }
+                }
+                flush();
+                if (has_ch) {
+                    const float den = round_to<T>(a.weighted_avg ? (float)patches : (float)n);
+                    const Pack<T, VC> prev = acc;
+                    pack_fill(acc, [&](int e) { return prev.get(e) / den; });
+                    store_pack_buf<T, VC>(desc(a.feat_out, r.out), voff, acc);
+                }
+                first_pass = false;
+            }
+            if (wave == 0 && a.npatch_out && lane == 0) {
+                if (a.idx_out) a.idx_out[r.out] = origin;
+                a.npatch_out[r.out] = patches;
+                int32_t* o = a.tlbr_out + (int64_t)r.out * 5;
+                o[0] = t; o[1] = y1; o[2] = x1; o[3] = y2; o[4] = x2;
+            }
+        }
     }
 }
 
 hipError_t launch_group_mean(const TemporalArgs& a, const BatchPtrs& bp, int n_videos, hipStream_t stream) {
     const int grid = a.T * a.gm_split;
     const bool mem2 = a.max_slots > 16 * a.T;          // root cells of more than 16 leaves (4-level trees and deeper)
-#define STTM_LAUNCH_GM(TT, VV) do { if (mem2) hipLaunchKernelGGL((k_group_mean<TT, VV, 5, true>), dim3(grid, n_videos), dim3(256), 0, stream, a, bp); \
-                                    else hipLaunchKernelGGL((k_group_mean<TT, VV, 6, false>), dim3(grid, n_videos), dim3(256), 0, stream, a, bp); } while (0)
+    // root cells of more than 64 leaves (5- / 6-level trees): long groups go to the whole workgroup (COOP).  Same-box A/B
+    // (profiles/r04z_k5_coop_ab.txt): 27 x 27 root 0, T = 64: K5 88.5 -> 64.0 us; 36 x 64 root 0, T = 16: 40.5 -> 41.3; on the
+    // 64-leaf root cells of the 20 x 36 / 18 x 26 grids 37.0 -> 39.4 / 40.1 -> 39.6 us -- their member time is many medium groups,
+    // not a few long ones --, so those keep the plain two-members-in-flight kernel.
+    const bool deep = a.max_slots > 64 * a.T;
+#define STTM_LAUNCH_GM(TT, VV) do { if (deep) hipLaunchKernelGGL((k_group_mean<TT, VV, 4, true, true>), dim3(grid, n_videos), dim3(256), 0, stream, a, bp); \
+                                    else if (mem2) hipLaunchKernelGGL((k_group_mean<TT, VV, 5, true, false>), dim3(grid, n_videos), dim3(256), 0, stream, a, bp); \
+                                    else hipLaunchKernelGGL((k_group_mean<TT, VV, 6, false, false>), dim3(grid, n_videos), dim3(256), 0, stream, a, bp); } while (0)
     if (a.dtype == STTM_F32) {
         if (a.vec == 8) STTM_LAUNCH_GM(float, 8); else if (a.vec == 4) STTM_LAUNCH_GM(float, 4); else if (a.vec == 2) STTM_LAUNCH_GM(float, 2); else STTM_LAUNCH_GM(float, 1);
     } else if (a.dtype == STTM_BF16) {
