@@ -141,6 +141,9 @@ CONFIGS = [
     ("C5 T=180 14x14x1024 f32 STTM(0.94,0.82)", 180, 1024, 14, 14, "float32", 0.94, 0.82),
     ("prod T=128 14x14x3584 bf16 STTM(0.85,0.55)", 128, 3584, 14, 14, "bfloat16", 0.85, 0.55),
     ("prod T=128 14x14x8192 bf16 STTM(0.85,0.55)", 128, 8192, 14, 14, "bfloat16", 0.85, 0.55),
+    # not a BASELINE configuration: 6-level trees (a 9th entry = root_level; 36 x 64 tokens at root_level 0: root cells of up to 32 x 32
+    # leaves), the shape the round-3 review measures the several-workgroups-per-root-cell spatial stage on
+    ("deep T=16 36x64x1024 f32 STTM(0.85,0.55) root_level 0 (6-level trees)", 16, 1024, 36, 64, "float32", 0.85, 0.55, 0),
 ]
 
 
@@ -154,17 +157,19 @@ def run_configs(dev, rank, world, timed, log):
     from sttm_amd.synth import synth_video
     from sttm_amd.tome_interface import get_tome_features
     out = []
-    for name, T, C, H, W, dtn, thr, tthr in CONFIGS:
+    for cfg in CONFIGS:
+        name, T, C, H, W, dtn, thr, tthr = cfg[:8]
+        root = cfg[8] if len(cfg) > 8 else 1
         dt = getattr(torch, dtn)
         eb = 4 if dt == torch.float32 else 2
         npool = max(3, int(-(-300e6 // (eb * C * T * H * W))))
         pool = [synth_video(T, C, H, W, seed=7000 + 100 * rank + i, dtype=dt, device=dev, gen_device=dev) for i in range(npool)]
-        kept = [get_quadtree_features(x, thr, tthr, 1)[0].shape[0] for x in pool]          # warm-up + N' of each
+        kept = [get_quadtree_features(x, thr, tthr, root)[0].shape[0] for x in pool]       # warm-up + N' of each
         reps = max(24, 2 * npool, min(300, int(0.25 / (5e-8 * T * H * W * C / 1024 + 2e-5))))
 
-        def run(pool=pool, reps=reps, thr=thr, tthr=tthr, npool=npool):
+        def run(pool=pool, reps=reps, thr=thr, tthr=tthr, npool=npool, root=root):
             for i in range(reps):
-                get_quadtree_features(pool[i % npool], thr, tthr, 1)
+                get_quadtree_features(pool[i % npool], thr, tthr, root)
         vps = timed(run, reps) / world                                                      # per GPU
         n_out = sum(kept) / len(kept)
         B = eb * C * T * H * W + eb * C * n_out + 24 * n_out
