@@ -1427,6 +1427,8 @@ __global__ void __launch_bounds__(256, OCC) k_group_mean(const TemporalArgs a0, 
     constexpr int NB = 4;                                       // 64-slot chunks whose metadata is loaded together
     constexpr int U0 = 64 / (eb * VEC), U = U0 < 1 ? 1 : (U0 > 8 ? 8 : U0);   // chunks of a row in flight per lane (64 bytes; narrow packs: 8 chunks)
     constexpr int CH = U * 64 * VEC;
+    constexpr int NBS = (COOP && U <= 4) ? 4 : 1;               // label chunks per step of a survivor's member scan (COOP = root cells of > 64 leaves;
+                                                                // eight chunks, or four next to eight row pieces per lane, do not fit the registers)
     // rows before this frame: frame_cnt[0 .. t), four words per lane and batch, all requested before the first is used
     int row0 = 0;
     for (int f0 = 0; f0 < t; f0 += 256) {
@@ -1508,14 +1510,27 @@ __global__ void __launch_bounds__(256, OCC) k_group_mean(const TemporalArgs a0, 
                     const Column col = column_from_geo(a, r.geo);
                     const int slot0 = t * col.A + (y1 - col.Y1) * col.aw + (x1 - col.X1);
                     int found = 0;
-                    for (int sb = slot0 + 1; found < n - 1 && sb < col.slots; sb += 64) {
-                        const int sl = sb + lane;
-                        const int slc = sl < col.slots ? sl : col.slots - 1;
-                        const int mr0 = slot_to_row(a, col, slc);
-                        const int lb = a.lab_row[mr0];
-                        const uint32_t q = a.meta[mr0];
-                        const int mrow = sl < col.slots ? mr0 : -1;
-                        const bool hit = mrow >= 0 && lb == origin;
+                    // (NBS label chunks of 64 slots per round trip: on root cells of more than 64 leaves the next frame's members are
+                    // A / 64 chunks away -- 16 steps per frame on 6-level trees, where the scan was 26 of the kernel's 58 us in the
+                    // development build's ablation, tools/k5_ablate.py modes 1 / 2)
+                    for (int sb = slot0 + 1; found < n - 1 && sb < col.slots; sb += 64 * NBS) {
+                        int lbs[NBS], mrows[NBS];
+                        uint32_t qs[NBS];
+#pragma unroll
+                        for (int b = 0; b < NBS; ++b) {
+                            const int sl = sb + b * 64 + lane;
+                            const int slc = sl < col.slots ? sl : col.slots - 1;
+                            const int mr0 = slot_to_row(a, col, slc);
+                            lbs[b] = a.lab_row[mr0];
+                            qs[b] = a.meta[mr0];
+                            mrows[b] = sl < col.slots ? mr0 : -1;
+                        }
+#pragma unroll
+                        for (int b = 0; b < NBS; ++b) {
+                        const int sl = sb + b * 64 + lane;
+                        const int mrow = mrows[b];
+                        const uint32_t q = qs[b];
+                        const bool hit = mrow >= 0 && lbs[b] == origin;
                         unsigned long long mm = __ballot(hit);
                         if (mm == 0ull) continue;
                         int ar = 0;
@@ -1563,6 +1578,7 @@ __global__ void __launch_bounds__(256, OCC) k_group_mean(const TemporalArgs a0, 
                                 if (cb0 == 0) patches += ak1;
                             }
                         }
+                        }   // chunk b
                     }
                 }
                 if (a.weighted_avg || n > 1) {
