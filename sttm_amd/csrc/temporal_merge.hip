@@ -1427,7 +1427,7 @@ __global__ void __launch_bounds__(256, OCC) k_group_mean(const TemporalArgs a0, 
     constexpr int NB = 4;                                       // 64-slot chunks whose metadata is loaded together
     constexpr int U0 = 64 / (eb * VEC), U = U0 < 1 ? 1 : (U0 > 8 ? 8 : U0);   // chunks of a row in flight per lane (64 bytes; narrow packs: 8 chunks)
     constexpr int CH = U * 64 * VEC;
-    constexpr int NBS = (COOP && U <= 4) ? 4 : 1;               // label chunks per step of a survivor's member scan (COOP = root cells of > 64 leaves;
+    constexpr int NBS = (MEM2 && U <= 4) ? ((COOP || eb == 4) ? 4 : 2) : 1;             // label chunks per step of a survivor's member scan (MEM2 = root cells of > 16 leaves;
                                                                 // eight chunks, or four next to eight row pieces per lane, do not fit the registers)
     // rows before this frame: frame_cnt[0 .. t), four words per lane and batch, all requested before the first is used
     int row0 = 0;
