@@ -101,7 +101,7 @@ int sttm_quadtree_merge(const void* x, int64_t stride_t, int64_t stride_c, int64
 /*
  * The spatial stage alone (SURVEY Appendix E's `sttm_quadtree_spatial`): quadtree_build_video with temporal_thresh <= 0 -- per-frame
  * pyramid, split decisions and node emission (quadtree_builder.py:85-215), nodes in (t, y1, x1) order.  Same buffers as
- * sttm_quadtree_merge; counts[STTM_CNT_OUT] = number of nodes.  (The temporal stage has no stand-alone entry point: it reads the
+ * sttm_quadtree_merge; counts[STTM_CNT_OUT] = number of nodes.  (The temporal stage's stand-alone entry point is sttm_temporal_merge below; inside the merge it reads the
  * node tables the spatial kernel leaves in the workspace -- root-cell node lists, inverse norms, default labels -- not a caller's
  * node list; cross_frame_node_merging_fast is never called on its own by the reference's L1, quadtree_builder.py:217-223.)
  */
@@ -109,6 +109,20 @@ int sttm_quadtree_spatial(const void* x, int64_t stride_t, int64_t stride_c, int
                           int T, int C, int H, int W, int dtype, float threshold, int root_level, int weighted_avg, int head_dim,
                           void* workspace, size_t workspace_bytes, void* feat_out, int32_t* npatch_out, int32_t* tlbr_out, int32_t* counts,
                           void* stream);
+
+/* The temporal stage alone, on a caller's node list: cross_frame_node_merging_fast / _slow of the reference
+ * (token_merging_utils/quadtree_temporal_merger.py:271-299; the second name SURVEY Appendix E proposed).
+ *   node_feat   [n_nodes, C] contiguous rows (dtype as below), node_tlbr  int32 [n_nodes, 5] = (t, y1, x1, y2, x2), y2 / x2 exclusive
+ *   T, H, W, root_level   the token grid and the root level the nodes come from: every box must be a cell of that quadtree partition
+ *                         (what quadtree_build_video / sttm_quadtree_spatial emit), at most one node per origin (t, y1, x1); boxes
+ *                         outside the grid or more nodes than leaves in a root cell set counts[STTM_CNT_OVERFLOW]
+ *   temporal_thresh <= 0  no merging: the nodes come back sorted by (t, y1, x1)
+ * Workspace, outputs, counts and error codes as sttm_quadtree_merge (size: sttm_quadtree_workspace_bytes for the same grid); whole-vector
+ * cosine only.  The node rows are copied once (into the origin-row layout of the merge); num_patches are the box areas. */
+int sttm_temporal_merge(const void* node_feat, const int32_t* node_tlbr, int n_nodes, int T, int C, int H, int W, int dtype,
+                        float temporal_thresh, int root_level, int weighted_avg, int slow_ver,
+                        void* workspace, size_t workspace_bytes, void* feat_out, int32_t* npatch_out, int32_t* tlbr_out, int32_t* counts,
+                        void* stream);
 
 /*
  * Same merge, but the counts are ALSO published into `counts_host` -- int32[STTM_CNT_SLOTS] of pinned, device-mapped

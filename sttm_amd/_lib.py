@@ -32,6 +32,7 @@ SIGNATURES = {
     "sttm_quadtree_merge": (_i, [_vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _f, _i, _i, _i, _i,
                                  _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     "sttm_quadtree_spatial": (_i, [_vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "sttm_temporal_merge": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     "sttm_quadtree_merge_async": (_i, [_vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _f, _i, _i, _i, _i,
                                        _vp, _sz, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "sttm_quadtree_merge_batch": (_i, [_i, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _f, _i, _i, _i, _i,

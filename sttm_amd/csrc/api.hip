@@ -314,6 +314,9 @@ void mark(void* const* events, int i, hipStream_t s) {
     if (events && events[i]) hipEventRecord(reinterpret_cast<hipEvent_t>(events[i]), s);
 }
 
+// a caller's node list for the stand-alone temporal stage (sttm_temporal_merge)
+struct NodeList { const void* feat; const int32_t* tlbr; int n; };
+
 // The merge of up to kBatchMax same-shaped videos in one set of launches.
 int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c, int64_t stride_h, int64_t stride_w,
                 int T, int C, int H, int W, int dtype,
@@ -321,9 +324,11 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
                 void* workspace, size_t workspace_stride,
                 void* const* feat_out, int32_t* const* npatch_out, int32_t* const* tlbr_out, int32_t* counts,
                 int32_t* counts_host, int seq, void* const* events, hipStream_t stream,
-                uint64_t* early_host = nullptr, int* n_early = nullptr, int flags = 0, int32_t* idx_out = nullptr) {
+                uint64_t* early_host = nullptr, int* n_early = nullptr, int flags = 0, int32_t* idx_out = nullptr,
+                const NodeList* nodes = nullptr) {
     if (n_early) *n_early = 0;
     if (!x || !workspace || !feat_out || !npatch_out || !tlbr_out || !counts) return fail(STTM_ERR_ARG, "null pointer argument");
+    if (nodes && (nv != 1 || head_dim != 0)) return fail(STTM_ERR_UNSUPPORTED, "the stand-alone temporal stage takes one video and the whole-vector cosine");
     if (T < 1 || C < 1) return fail(STTM_ERR_ARG, "T and C must be positive");
     if (dtype < 0 || dtype > 2) return fail(STTM_ERR_ARG, "unknown dtype code %d", dtype);
     if (stride_c != 1) return fail(STTM_ERR_ARG, "channel stride must be 1 (channels-last view); got %lld", (long long)stride_c);
@@ -336,7 +341,7 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
     if (workspace_stride < p.bytes) return fail(STTM_ERR_ARG, "workspace too small: %zu < %zu", workspace_stride, p.bytes);
     if (reinterpret_cast<uintptr_t>(workspace) % 256 || (nv > 1 && workspace_stride % 256))
         return fail(STTM_ERR_ARG, "workspace (and the per-video stride) must be 256-byte aligned");
-    if (weighted_avg) {
+    if (weighted_avg && !nodes) {           // (the sum-pool pyramid of the spatial stage; the temporal stage weights by box areas only)
         for (int l = 1; l < D; ++l)
             if ((p.dims.h[l] & 1) != (p.dims.w[l] & 1))
                 return fail(STTM_ERR_PARITY, "weighted_avg needs equal parities at every pooled level; level %dx%d is mixed",
@@ -382,7 +387,7 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
     sa.sum_mode = weighted_avg ? 1 : 0;
     sa.n_head = n_head; sa.head_lanes = head_lanes;
     // dense [T*H*W, C] input: the rows of 1x1 nodes are read from x by the later kernels instead of being copied to S
-    const bool dense = stride_w == C && stride_h == (int64_t)W * C && stride_t == (int64_t)H * W * C;
+    const bool dense = !nodes && stride_w == C && stride_h == (int64_t)W * C && stride_t == (int64_t)H * W * C;
     sa.leaves_in_x = dense ? 1 : 0;
     sa.k1_var = cfg.k1_var;
     sa.S = b.S; sa.meta = b.meta; sa.inrm = b.inrm; sa.rc_list = b.rc_list;
@@ -447,7 +452,10 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
     if (!tops && p.dims.n_level >= 6 && nt > 768)
         return fail(STTM_ERR_UNSUPPORTED, "a %d-level tree with %d lanes per token row does not fit the LDS in the one-workgroup form "
                     "(per-head cosine or k1_split = -1; 6-level trees: <= 768 lanes, i.e. fp32 C <= 3072, 16-bit C <= 6144)", p.dims.n_level, nt);
-    if ((e = sttm::launch_spatial(sa, bp, nv, dtype, vec, nt, stream, tops)) != hipSuccess)
+    if (nodes) {
+        if ((e = sttm::launch_ingest_nodes(ta, nodes->feat, nodes->tlbr, nodes->n, b.S, b.meta, b.inrm, b.rc_list, b.cgeo, stream)) != hipSuccess)
+            return fail(STTM_ERR_LAUNCH, "node ingest: %s", hipGetErrorString(e));
+    } else if ((e = sttm::launch_spatial(sa, bp, nv, dtype, vec, nt, stream, tops)) != hipSuccess)
         return fail(STTM_ERR_LAUNCH, "spatial kernel: %s", hipGetErrorString(e));
     mark(events, 1, stream);
 #ifdef STTM_DEV
@@ -540,6 +548,20 @@ int sttm_quadtree_spatial(const void* x, int64_t stride_t, int64_t stride_c, int
     // the spatial stage alone = the merge with the temporal stage switched off (quadtree_builder.py:217: `if temporal_thresh > 0`)
     return sttm_quadtree_merge(x, stride_t, stride_c, stride_h, stride_w, T, C, H, W, dtype, threshold, -1.0f, root_level, weighted_avg,
                                head_dim, 0, workspace, workspace_bytes, feat_out, npatch_out, tlbr_out, counts, stream_);
+}
+
+int sttm_temporal_merge(const void* node_feat, const int32_t* node_tlbr, int n_nodes, int T, int C, int H, int W, int dtype,
+                        float temporal_thresh, int root_level, int weighted_avg, int slow_ver,
+                        void* workspace, size_t workspace_bytes, void* feat_out, int32_t* npatch_out, int32_t* tlbr_out, int32_t* counts,
+                        void* stream_) {
+    // cross_frame_node_merging_fast / _slow on a caller's node list (quadtree_temporal_merger.py:271-299): the nodes are brought into
+    // the layout of the spatial stage's outputs, then the pair, label and group-mean kernels of the full merge run unchanged
+    if (!node_feat || !node_tlbr) return fail(STTM_ERR_ARG, "null node list");
+    if (n_nodes < 0 || (int64_t)n_nodes > (int64_t)T * H * W) return fail(STTM_ERR_ARG, "n_nodes = %d outside [0, T*H*W]", n_nodes);
+    const NodeList nodes{node_feat, node_tlbr, n_nodes};
+    return merge_group(1, &node_feat, (int64_t)H * W * C, 1, (int64_t)W * C, C, T, C, H, W, dtype, 2.0f, temporal_thresh, root_level,
+                       weighted_avg, 0, slow_ver, workspace, workspace_bytes, &feat_out, &npatch_out, &tlbr_out, counts,
+                       nullptr, 0, nullptr, reinterpret_cast<hipStream_t>(stream_), nullptr, nullptr, 0, nullptr, &nodes);
 }
 
 int sttm_quadtree_merge_async(const void* x, int64_t stride_t, int64_t stride_c, int64_t stride_h, int64_t stride_w,

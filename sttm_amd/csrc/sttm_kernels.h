@@ -169,6 +169,9 @@ bool labels_can_fuse(const TemporalArgs& a, int n_videos);
 bool labels_can_fold(const TemporalArgs& a, int n_videos, int* cap);
 hipError_t launch_labels_fused(const TemporalArgs& a, const BatchPtrs& bp, int n_videos, hipStream_t stream);
 hipError_t launch_group_mean(const TemporalArgs& a, const BatchPtrs& bp, int n_videos, hipStream_t stream);
+// stand-alone temporal stage: a caller's node list -> the layout the spatial kernel leaves behind (single video)
+hipError_t launch_ingest_nodes(const TemporalArgs& a, const void* feat, const int32_t* tlbr, int n_nodes, void* S, uint32_t* meta,
+                               double* inrm, int* rc_list, uint32_t* cgeo, hipStream_t stream);
 size_t colscratch_ints(int T, int H, int W, int R);
 void pairs_shape(int T, int R, int fold, int want_seg, int want_nt, int* seg, int* nt);
 

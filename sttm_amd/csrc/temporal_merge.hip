@@ -1730,6 +1730,94 @@ __global__ void __launch_bounds__(256, OCC) k_group_mean(const TemporalArgs a0, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Stand-alone temporal stage (sttm_temporal_merge = cross_frame_node_merging_fast / _slow on a caller's node list,
+// quadtree_temporal_merger.py:271-299): the node list [N, C] + [N, 5] is brought into the layout the spatial kernel leaves behind --
+// features at their origin rows of S, box / inverse norm / default label / default group size by origin row, a node list per
+// (frame, root cell), the geometry table, zeroed counters -- and the pair, label and group-mean kernels run unchanged.
+// One workgroup per node copies the row and sums its squares on the way (fp32 per lane, fixed-order tree over the lanes and waves).
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) k_ingest_nodes(const TemporalArgs a, const void* feat, const int32_t* tlbr, int n_nodes,
+                                                      void* S, uint32_t* meta, double* inrm, int* rc_list) {
+    __shared__ float wsum[4];
+    const int i = blockIdx.x;
+    if (i >= n_nodes) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = tlbr[5 * i], y1 = tlbr[5 * i + 1], x1 = tlbr[5 * i + 2], y2 = tlbr[5 * i + 3], x2 = tlbr[5 * i + 4];
+    const bool ok = t >= 0 && t < a.T && y1 >= 0 && x1 >= 0 && y2 > y1 && x2 > x1 && y2 <= a.H && x2 <= a.W;
+    if (!ok) {                          // (uniform) a box outside the grid: the call reports an overflow, nothing is written
+        if (tid == 0) __hip_atomic_fetch_or(a.bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const int64_t row = (int64_t)t * a.H * a.W + y1 * a.W + x1;
+    float acc = 0.f;
+    for (int c = tid; c < a.C; c += 256) {
+        float v;
+        if constexpr (TypeInfo<T>::bytes == 4) {
+            v = reinterpret_cast<const float*>(feat)[(int64_t)i * a.C + c];
+            reinterpret_cast<float*>(S)[row * a.C + c] = v;
+        } else {
+            const uint16_t bits = reinterpret_cast<const uint16_t*>(feat)[(int64_t)i * a.C + c];
+            reinterpret_cast<uint16_t*>(S)[row * a.C + c] = bits;
+            if constexpr (std::is_same<T, bf16_t>::value) v = bf16_bits_to_float(bits);
+            else v = f16_bits_to_float(bits);
+        }
+        acc += v * v;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) wsum[wave] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        const float n2 = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+        meta[row] = ((uint32_t)y2 << 16) | (uint32_t)x2;
+        inrm[row] = 1.0 / (sqrt((double)n2) + 1e-8);
+        a.lab_row[row] = (int32_t)row;
+        a.gcnt[row] = 1;
+        const int rcell = root_cell_of(a.dims, y1, x1);
+        int* list = rc_list + ((int64_t)t * a.R + rcell) * a.rc_stride;
+        const bool one = y2 - y1 == 1 && x2 - x1 == 1;
+        const int old = atomicAdd(list, 1 + (one ? 1 << 16 : 0));
+        const int pos = old & 0xffff;
+        if (pos < a.rc_stride - 1) list[1 + pos] = (y1 << 24) | (x1 << 16) | (y2 << 8) | x2;
+        else __hip_atomic_fetch_or(a.bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // more nodes than leaves in a root cell
+    }
+}
+// geometry table + the counters the spatial kernel zeroes
+__global__ void __launch_bounds__(256) k_ingest_geo(const TemporalArgs a, uint32_t* cgeo) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p < a.H * a.W) {
+        const int y = p / a.W, x = p - y * a.W;
+        const int r = root_cell_of(a.dims, y, x);
+        const Column c = make_column(a, a.dims, r);
+        cgeo[p] = (uint32_t)c.Y1 | ((uint32_t)c.X1 << 8) | ((uint32_t)c.aw << 16) | ((uint32_t)c.ah << 24);
+    }
+    if (p < a.T) a.frame_cnt[p] = 0;
+    if (p < a.R) a.col_arrive[p] = 0;
+    if (p < STTM_CNT_SLOTS) a.counts[p] = 0;
+}
+hipError_t launch_ingest_nodes(const TemporalArgs& a, const void* feat, const int32_t* tlbr, int n_nodes, void* S, uint32_t* meta,
+                               double* inrm, int* rc_list, uint32_t* cgeo, hipStream_t stream) {
+    const size_t N = (size_t)a.T * a.H * a.W;
+    hipError_t e;
+    // every origin row starts as "no node here"; the node lists start empty; bar: overflow flag / N' word / barrier word
+    if ((e = hipMemsetAsync(meta, 0, N * 4, stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(a.gcnt, 0, N * 4, stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(a.lab_row, 0xff, N * 4, stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(rc_list, 0, (size_t)a.T * a.R * a.rc_stride * 4, stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(a.bar, 0, 32, stream)) != hipSuccess) return e;
+    int most = a.H * a.W;
+    if (a.T > most) most = a.T;
+    if (a.R > most) most = a.R;
+    hipLaunchKernelGGL(k_ingest_geo, dim3((most + 255) / 256), dim3(256), 0, stream, a, cgeo);
+    if (n_nodes > 0) {
+        if (a.dtype == STTM_F32) hipLaunchKernelGGL((k_ingest_nodes<float>), dim3(n_nodes), dim3(256), 0, stream, a, feat, tlbr, n_nodes, S, meta, inrm, rc_list);
+        else if (a.dtype == STTM_BF16) hipLaunchKernelGGL((k_ingest_nodes<bf16_t>), dim3(n_nodes), dim3(256), 0, stream, a, feat, tlbr, n_nodes, S, meta, inrm, rc_list);
+        else hipLaunchKernelGGL((k_ingest_nodes<f16_t>), dim3(n_nodes), dim3(256), 0, stream, a, feat, tlbr, n_nodes, S, meta, inrm, rc_list);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_group_mean(const TemporalArgs& a, const BatchPtrs& bp, int n_videos, hipStream_t stream) {
     const int grid = a.T * a.gm_split;
     const bool mem2 = a.max_slots > 16 * a.T;          // root cells of more than 16 leaves (4-level trees and deeper)

@@ -553,3 +553,61 @@ def get_quadtree_features_into(dest, _video_feature, threshold, temporal_thresh=
 
 
 get_quadtree_features_into.returns_idx = True        # patch_hooks._merge_concat asks for merged_token_1d_idx along with the merge
+
+
+def cross_frame_node_merging_fast(quadtree_features_video, quadtree_tyxyx_tlbr, temporal_thresh, quadtree_num_patches_per_node=None,
+                                  weighted_avg=False, head_dim=None, *, grid, root_level, slow_ver=False):
+    """The temporal stage alone on a node list (reference: `cross_frame_node_merging_fast` / `_slow`,
+    token_merging_utils/quadtree_temporal_merger.py:271-299; C ABI: `sttm_temporal_merge`).
+
+    quadtree_features_video [N, C] (float32 / bfloat16 / float16) and quadtree_tyxyx_tlbr [N, 5] = (t, y1, x1, y2, x2) are the
+    nodes the spatial stage emits (`get_quadtree_features(..., temporal_thresh=-1)`); `grid = (T, H, W)` and `root_level` name the
+    quadtree partition they come from (the reference function derives neither: it compares every pair of boxes; here the nodes go
+    into the per-root-cell tables of the fused merge, so every box must be a cell of that partition).  `quadtree_num_patches_per_node`
+    is accepted for signature compatibility: the patch counts are the box areas.  Returns (features [N', C], num_patches [N'],
+    tlbr [N', 5]) ordered by (t, y1, x1), like `agg_feature_and_metadata`."""
+    if head_dim is not None:
+        raise NotImplementedError("the stand-alone temporal stage uses the whole-vector cosine (head_dim=None); "
+                                  "get_quadtree_features(..., head_dim=...) runs the per-head variant inside the merge")
+    x, tl = quadtree_features_video, quadtree_tyxyx_tlbr
+    if not x.is_cuda:
+        raise RuntimeError("sttm_amd runs on the GPU only: the input must be a CUDA (ROCm) tensor; there is no CPU fallback")
+    if x.dtype not in _DTYPE_CODE:
+        raise NotImplementedError(f"dtype {x.dtype} is not supported (float32, bfloat16, float16)")
+    T, H, W = (int(v) for v in grid)
+    N, C = x.shape
+    if tl.shape != (N, 5):
+        raise ValueError(f"tlbr must be [N, 5]; got {tuple(tl.shape)} for N = {N}")
+    lib = _lib.load()
+    dev = x.device
+    x = x.contiguous()
+    tl = tl.to(device=dev, dtype=torch.int32).contiguous()
+    code = _DTYPE_CODE[x.dtype]
+    with torch.cuda.device(dev):
+        nbytes = lib.sttm_quadtree_workspace_bytes(T, H, W, C, code, int(root_level))
+        if nbytes == 0:
+            _lib.raise_for(_lib.ERR_INDEX if "root_level" in _lib.last_error() else _lib.ERR_ARG)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        rows = max(N, 1)
+        feat = torch.empty((rows, C), dtype=x.dtype, device=dev)
+        npatch = torch.empty(rows, dtype=torch.int32, device=dev)
+        tlbr = torch.empty((rows, 5), dtype=torch.int32, device=dev)
+        counts = torch.zeros(_lib.CNT_SLOTS, dtype=torch.int32, device=dev)
+        rc = lib.sttm_temporal_merge(x.data_ptr(), tl.data_ptr(), N, T, C, H, W, code, float(temporal_thresh), int(root_level),
+                                     1 if weighted_avg else 0, 1 if slow_ver else 0, ws.data_ptr(), nbytes,
+                                     feat.data_ptr(), npatch.data_ptr(), tlbr.data_ptr(), counts.data_ptr(),
+                                     torch.cuda.current_stream(dev).cuda_stream)
+        _lib.raise_for(rc)
+        cnt = counts.cpu().tolist()
+    if cnt[_lib.CNT_OVERFLOW]:
+        raise RuntimeError(f"sttm_temporal_merge: invalid node list (overflow flags {cnt[_lib.CNT_OVERFLOW]}): boxes outside the "
+                           f"{H} x {W} grid, or nodes that are not cells of the root_level = {root_level} partition")
+    n = cnt[_lib.CNT_OUT]
+    return feat[:n], npatch[:n], tlbr[:n]
+
+
+def cross_frame_node_merging_slow(quadtree_features_video, quadtree_tyxyx_tlbr, temporal_thresh, quadtree_num_patches_per_node=None,
+                                  weighted_avg=False, head_dim=None, *, grid, root_level):
+    """`cross_frame_node_merging_slow` (quadtree_temporal_merger.py:289-299): the similarity-sorted pair filter."""
+    return cross_frame_node_merging_fast(quadtree_features_video, quadtree_tyxyx_tlbr, temporal_thresh, quadtree_num_patches_per_node,
+                                         weighted_avg, head_dim, grid=grid, root_level=root_level, slow_ver=True)

@@ -429,6 +429,55 @@ def test_stand_alone_spatial_entry_point():
     _check((feat[:n], npatch[:n], tlbr[:n]), exp, FP32_TOL, "sttm_quadtree_spatial")
 
 
+TEMPORAL_ONLY_CASES = [
+    # (T, C, H, W, seed, dtype, threshold of the spatial stage that makes the node list, temporal, root_level, weighted, slow)
+    (8, 1024, 14, 14, 60, torch.float32, 0.85, 0.55, 1, False, False),
+    (6, 256, 14, 14, 61, torch.float32, 0.80, 0.50, 1, True, False),
+    (6, 256, 14, 14, 62, torch.float32, 0.85, 0.55, 1, False, True),       # cross_frame_node_merging_slow
+    (5, 128, 20, 36, 63, torch.bfloat16, 0.85, 0.60, 1, False, False),     # 4-level partition
+    (4, 96, 27, 27, 64, torch.float16, 0.80, 0.50, 0, False, False),       # 5-level partition
+    (5, 64, 14, 14, 65, torch.float32, 0.85, -1.0, 1, False, False),       # no merging: the nodes come back in order
+    (64, 1024, 14, 14, 66, torch.float32, 0.85, 0.65, 1, False, False),    # BASELINE config 2 size
+]
+
+
+@pytest.mark.parametrize("case", TEMPORAL_ONLY_CASES, ids=lambda c: "T%d_C%d_%dx%d_s%d" % c[:5])
+def test_stand_alone_temporal_stage_on_a_node_list(case):
+    """`cross_frame_node_merging_fast` / `_slow` on a caller's node list (quadtree_temporal_merger.py:271-299; C ABI
+    `sttm_temporal_merge`): the node list is the ORACLE's spatial stage, the expectation the oracle's `temporal_merge` on it -- and
+    the result equals the fused merge of the same video."""
+    from oracle import sttm_oracle as O
+    from sttm_amd import get_quadtree_features
+    from sttm_amd.quadtree_interface import cross_frame_node_merging_fast, cross_frame_node_merging_slow
+    from sttm_amd.synth import synth_video
+    T, C, H, W, seed, dtype, thr, tthr, root, weighted, slow = case
+    x = synth_video(T, C, H, W, seed=seed, dtype=dtype)
+    nf, nn, nt = O.get_quadtree_features(x, thr, -1.0, root, weighted)                    # the node list
+    exp = O.temporal_merge(nf, nt, nn, tthr, weighted, None, slow) if tthr > 0 else (nf, nn, nt)
+    fn = cross_frame_node_merging_slow if slow else cross_frame_node_merging_fast
+    out = fn(nf.to(_dev()), nt.to(_dev()), tthr, nn.to(_dev()), weighted, None, grid=(T, H, W), root_level=root)
+    tol = FP32_TOL if dtype == torch.float32 else BF16_TOL
+    _check(out, exp[:3], tol, "stand-alone temporal stage")
+    if tthr > 0:
+        fused = get_quadtree_features(x.to(_dev()), thr, tthr, root, weighted, slow_ver=slow)
+        assert torch.equal(out[2], fused[2]) and torch.equal(out[1], fused[1])
+    # a shuffled node list gives the same result (origins, not list positions, order the nodes)
+    perm = torch.randperm(nf.shape[0], generator=torch.Generator().manual_seed(seed))
+    out2 = fn(nf[perm].to(_dev()), nt[perm].to(_dev()), tthr, None, weighted, None, grid=(T, H, W), root_level=root)
+    for a, b in zip(out, out2):
+        assert torch.equal(a, b)
+
+
+def test_stand_alone_temporal_stage_rejects_boxes_outside_the_grid():
+    from sttm_amd.quadtree_interface import cross_frame_node_merging_fast
+    feat = torch.randn(3, 64, device=_dev())
+    tl = torch.tensor([[0, 0, 0, 1, 1], [0, 0, 1, 1, 2], [1, 13, 13, 15, 15]], dtype=torch.int32, device=_dev())
+    with pytest.raises(RuntimeError, match="invalid node list"):
+        cross_frame_node_merging_fast(feat, tl, 0.5, None, grid=(2, 14, 14), root_level=1)
+    with pytest.raises(NotImplementedError):
+        cross_frame_node_merging_fast(feat, tl, 0.5, None, False, 32, grid=(2, 14, 14), root_level=1)
+
+
 def test_batched_extension_equals_per_video_calls():
     """get_quadtree_features_batch (sttm_quadtree_merge_batch: same-shaped videos share one set of launches) returns exactly what
     per-video calls return; mixed shapes are grouped, more than STTM_BATCH_MAX videos of a shape are issued in groups."""
