@@ -478,6 +478,32 @@ def test_stand_alone_temporal_stage_rejects_boxes_outside_the_grid():
         cross_frame_node_merging_fast(feat, tl, 0.5, None, False, 32, grid=(2, 14, 14), root_level=1)
 
 
+def test_stand_alone_temporal_stage_through_the_c_abi_error_codes():
+    """`sttm_temporal_merge` called directly (ctypes): argument errors come back as codes, nothing is launched."""
+    from sttm_amd import _lib
+    lib = _lib.load()
+    T, C, H, W = 2, 64, 14, 14
+    feat = torch.randn(4, C, device=_dev())
+    tl = torch.tensor([[0, 0, 0, 1, 1], [0, 0, 1, 1, 2], [1, 0, 0, 2, 2], [1, 2, 2, 4, 4]], dtype=torch.int32, device=_dev())
+    nbytes = lib.sttm_quadtree_workspace_bytes(T, H, W, C, 0, 1)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=_dev())
+    out = torch.empty((T * H * W, C), device=_dev()); npatch = torch.empty(T * H * W, dtype=torch.int32, device=_dev())
+    tlbr = torch.empty((T * H * W, 5), dtype=torch.int32, device=_dev()); counts = torch.zeros(_lib.CNT_SLOTS, dtype=torch.int32, device=_dev())
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def call(n_nodes, feat_ptr=feat.data_ptr(), ws_bytes=nbytes, root=1):
+        return lib.sttm_temporal_merge(feat_ptr, tl.data_ptr(), n_nodes, T, C, H, W, 0, 0.5, root, 0, 0, ws.data_ptr(), ws_bytes,
+                                       out.data_ptr(), npatch.data_ptr(), tlbr.data_ptr(), counts.data_ptr(), stream)
+    assert call(4) == 0
+    torch.cuda.synchronize()
+    c = counts.cpu().tolist()
+    assert c[_lib.CNT_OVERFLOW] == 0 and 1 <= c[_lib.CNT_OUT] <= 4
+    assert call(T * H * W + 1) == _lib.ERR_ARG
+    assert call(4, feat_ptr=None) == _lib.ERR_ARG
+    assert call(4, ws_bytes=nbytes // 2) == _lib.ERR_ARG
+    assert call(4, root=9) == _lib.ERR_INDEX
+
+
 def test_batched_extension_equals_per_video_calls():
     """get_quadtree_features_batch (sttm_quadtree_merge_batch: same-shaped videos share one set of launches) returns exactly what
     per-video calls return; mixed shapes are grouped, more than STTM_BATCH_MAX videos of a shape are issued in groups."""
