@@ -290,11 +290,15 @@ int octree_plan(int B, int side, int C, int dtype, int root_level, OctPlan* p) {
 }
 
 // Group-mean workgroups per frame: enough 4-wave workgroups (T * split) to cover the chip several times over.
-int gm_split_for(int T) {
+int gm_split_for(int T, int HW) {
     const int env = config().gm_split;
     const int want = env > 0 ? env : (4096 + T - 1) / T;
     int s = 1;
     while (s < want && s < 64) s <<= 1;          // a power of two: the kernel masks instead of dividing
+    // frames of 512 and more tokens: every workgroup of a frame ranks ALL its survivors before it takes its share, so fewer, longer
+    // shares are cheaper there (same-box sweep at T = 128: 20 x 36 tokens K5 36.3 -> 34.2 us with 16 instead of 32 per frame; 14 x 14 and
+    // 13 x 24 lose 1.1-1.3 us with 16, so they keep 32)
+    if (env <= 0 && HW >= 512 && s > 16) s = 16;
     return s;
 }
 
@@ -423,7 +427,7 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
     ta.ecap_magic = 0xffffffffu / (unsigned)p.ecap + 1u;
     ta.col_mask = b.col_mask; ta.col_arrive = b.col_arrive; ta.frame_cnt = b.frame_cnt; ta.bar = b.bar;
     ta.colscratch = b.colscratch;
-    ta.gm_split = gm_split_for(T); ta.lab_row = b.lab_row; ta.gcnt = b.gcnt; ta.cgeo = b.cgeo;
+    ta.gm_split = gm_split_for(T, H * W); ta.lab_row = b.lab_row; ta.gcnt = b.gcnt; ta.cgeo = b.cgeo;
     ta.counts = counts;
     ta.counts_host = counts_host; ta.seq = seq;
     // every column reports its survivors to the host itself (single video, a slot per column)
@@ -663,7 +667,7 @@ int sttm_quadtree_apply(const void* v, int64_t stride_t, int64_t stride_c, int64
     ta.weighted_avg = sum_mode ? 1 : 0;
     ta.S = b.S; ta.xrows = dense ? v : nullptr;
     ta.frame_cnt = b.frame_cnt; ta.lab_row = b.lab_row; ta.gcnt = b.gcnt; ta.cgeo = b.cgeo;
-    ta.meta = b.meta; ta.gm_split = gm_split_for(T);
+    ta.meta = b.meta; ta.gm_split = gm_split_for(T, H * W);
     ta.counts = const_cast<int32_t*>(counts);
     ta.feat_out = out;
     sttm::BatchPtrs bp;
