@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STTM_ABI_VERSION 6
+#define STTM_ABI_VERSION 7
 
 #define STTM_F32 0
 #define STTM_BF16 1
@@ -113,14 +113,21 @@ int sttm_quadtree_spatial(const void* x, int64_t stride_t, int64_t stride_c, int
 /* The temporal stage alone, on a caller's node list: cross_frame_node_merging_fast / _slow of the reference
  * (token_merging_utils/quadtree_temporal_merger.py:271-299; the second name SURVEY Appendix E proposed).
  *   node_feat   [n_nodes, C] contiguous rows (dtype as below), node_tlbr  int32 [n_nodes, 5] = (t, y1, x1, y2, x2), y2 / x2 exclusive
- *   T, H, W, root_level   the token grid and the root level the nodes come from: every box must be a cell of that quadtree partition
- *                         (what quadtree_build_video / sttm_quadtree_spatial emit), at most one node per origin (t, y1, x1); boxes
- *                         outside the grid or more nodes than leaves in a root cell set counts[STTM_CNT_OVERFLOW]
- *   temporal_thresh <= 0  no merging: the nodes come back sorted by (t, y1, x1)
- * Workspace, outputs, counts and error codes as sttm_quadtree_merge (size: sttm_quadtree_workspace_bytes for the same grid); whole-vector
- * cosine only.  The node rows are copied once (into the origin-row layout of the merge); num_patches are the box areas. */
+ *   T, H, W, root_level   the token grid and the root level the nodes come from.  Every box must be ONE cell of that quadtree partition
+ *                         (what quadtree_build_video / sttm_quadtree_spatial emit) and the boxes of a frame must be disjoint.  A node
+ *                         that is not -- outside the grid, not a cell, a duplicated origin, overlapping another node, or more nodes
+ *                         than leaves in a root cell -- is left out and sets counts[STTM_CNT_OVERFLOW] (outputs invalid); the kernels
+ *                         stay inside their buffers whatever the list holds.
+ *   temporal_thresh       the pair filter keeps sim >= temporal_thresh, ALSO for thresholds <= 0 (quadtree_temporal_merger.py:70-71;
+ *                         it is quadtree_build_video that skips the stage for temporal_thresh <= 0, not this function)
+ *   head_dim              0 = whole-vector cosine; > 0 = per-head cosine averaged over heads (:65-68; ABI v7); ignored with slow_ver
+ *                         like cross_frame_node_merging_slow ignores it
+ * Workspace, outputs, counts and error codes as sttm_quadtree_merge (size: sttm_quadtree_workspace_bytes for the same grid).  The node
+ * rows are copied once (into the origin-row layout of the merge); num_patches are the box areas; outputs are ordered by (t, y1, x1) and a
+ * group is represented by its first node in that order (= the reference's lowest index when the list is sorted, as quadtree_build_video
+ * passes it). */
 int sttm_temporal_merge(const void* node_feat, const int32_t* node_tlbr, int n_nodes, int T, int C, int H, int W, int dtype,
-                        float temporal_thresh, int root_level, int weighted_avg, int slow_ver,
+                        float temporal_thresh, int root_level, int weighted_avg, int head_dim, int slow_ver,
                         void* workspace, size_t workspace_bytes, void* feat_out, int32_t* npatch_out, int32_t* tlbr_out, int32_t* counts,
                         void* stream);
 
@@ -193,7 +200,10 @@ int sttm_wait_counts_early(const int32_t* counts_host, const uint64_t* early_hos
  *                                       and a multiple of 256
  *   counts                              device int32[n_videos][STTM_CNT_SLOTS]
  *   counts_host                         NULL or pinned int32[n_videos][STTM_CNT_SLOTS]; video v publishes seq + v in its last slot
- * Any n_videos >= 1 (internally issued in groups of STTM_BATCH_MAX videos per launch set).
+ * Any n_videos >= 1.  Round 5 (stage-skewed form, default): the videos are dealt out to "batch_streams" internal streams (created on
+ * first use, per host thread and device) in launch sets of "batch_sub" videos, forked from and joined back into `stream` with events, so
+ * that consecutive videos sit in DIFFERENT stages at any moment; batch_streams <= 1 selects the lockstep form (every kernel once per
+ * group of STTM_BATCH_MAX videos on `stream` itself).  Both forms run the same kernels with the same per-video arguments.
  */
 #define STTM_BATCH_MAX 16
 int sttm_quadtree_merge_batch(int n_videos, const void* const* x, int64_t stride_t, int64_t stride_c, int64_t stride_h, int64_t stride_w,
@@ -226,6 +236,8 @@ int sttm_quadtree_merge_batch(int n_videos, const void* const* x, int64_t stride
  *                 2: the round-3 form of the slot-indexed stage (three barriers per iteration; A/B)
  *   "no_fuse"     1: stand-alone label stage as two launches (no in-kernel grid barrier)
  *   "force_gmem_labels"  1: label stage on global scratch instead of LDS (the path of columns too large for LDS)
+ *   "batch_streams" / "batch_sub"   sttm_quadtree_merge_batch: internal streams (default 3; <= 1 = lockstep form) and videos per launch
+ *                 set on a stream (default 1, at most STTM_BATCH_MAX)
  *   "tome_split"  ToMe match kernel for float32 inputs.  1 (default): unit rows as two fp16 planes (h + l of 4096 v, residual
  *                 <= 2^-23), scores from the products l.l + l.h + h.l + h.h on the fp16 matrix pipe with fp32 accumulation
  *                 (each product exact; error bound 2.4e-7 + the fp32 accumulation, measured <= 9.2e-7 against float64 where

@@ -8,13 +8,15 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # STTM_LIB=dev selects the development build (python -m sttm_amd.build --dev: measurement hooks for tools/, never the product)
-# (any other value of STTM_LIB = the file name of another build under sttm_amd/lib/: same-box A/B of two builds in tools/)
-_which = os.environ.get("STTM_LIB", "")
-LIB_PATH = os.path.join(_HERE, "lib", "libsttm_hip_dev.so" if _which == "dev" else (_which if _which.endswith(".so") else "libsttm_hip.so"))
+# (any other value of STTM_LIB = the FILE NAME of another build inside sttm_amd/lib/ -- same-box A/B of two builds in tools/; only the
+#  base name is used, so the variable cannot point the product binding at a shared object outside that directory)
+_which = os.path.basename(os.environ.get("STTM_LIB", ""))
+LIB_PATH = os.path.join(_HERE, "lib", "libsttm_hip_dev.so" if _which == "dev" else
+                        (_which if _which.startswith("libsttm_hip") and _which.endswith(".so") else "libsttm_hip.so"))
 
 STTM_F32, STTM_BF16, STTM_F16 = 0, 1, 2
 ERR_ARG, ERR_UNSUPPORTED, ERR_LAUNCH, ERR_INDEX, ERR_PARITY, ERR_TIMEOUT = -1, -2, -3, -4, -5, -6
-ABI_VERSION = 6            # STTM_ABI_VERSION of include/sttm_hip.h this binding was written for
+ABI_VERSION = 7            # STTM_ABI_VERSION of include/sttm_hip.h this binding was written for
 CNT_NODES, CNT_CANDIDATES, CNT_EDGES, CNT_OUT, CNT_ITERS, CNT_OVERFLOW, CNT_LEAFNODES, CNT_SLOTS = 0, 1, 2, 3, 4, 5, 6, 8
 OVF_BARRIER_TIMEOUT = 64   # STTM_OVF_BARRIER_TIMEOUT
 EVENT_SLOTS = 5            # STTM_EVENT_SLOTS
@@ -32,7 +34,7 @@ SIGNATURES = {
     "sttm_quadtree_merge": (_i, [_vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _f, _i, _i, _i, _i,
                                  _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     "sttm_quadtree_spatial": (_i, [_vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
-    "sttm_temporal_merge": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "sttm_temporal_merge": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     "sttm_quadtree_merge_async": (_i, [_vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _f, _i, _i, _i, _i,
                                        _vp, _sz, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "sttm_quadtree_merge_batch": (_i, [_i, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _f, _i, _i, _i, _i,

@@ -24,7 +24,8 @@ int fail(int code, const char* fmt, ...) {
 // Tuning / test switches: defaults from STTM_<KEY> environment variables, read ONCE; sttm_configure overrides them.
 // None of them changes results.
 struct Config {
-    int pairs_seg, pairs_nt, pairs_var, k1_var, k1_split, no_dense, gm_split, label_nt, vec16, vec32, fold_kb, fold_labels, no_fuse, force_gmem_labels, tome_split, tome_flat, tome_rank;
+    int pairs_seg, pairs_nt, pairs_var, k1_var, k1_split, no_dense, gm_split, label_nt, vec16, vec32, fold_kb, fold_labels, no_fuse, force_gmem_labels, tome_split, tome_flat, tome_rank,
+        batch_streams, batch_sub;
 };
 int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
@@ -50,6 +51,8 @@ Config& config() {
         d.tome_split = env_int("STTM_TOME_SPLIT", 1);
         d.tome_flat = env_int("STTM_TOME_FLAT", 1);
         d.tome_rank = env_int("STTM_TOME_RANK", 0);
+        d.batch_streams = env_int("STTM_BATCH_STREAMS", 3);
+        d.batch_sub = env_int("STTM_BATCH_SUB", 1);
         return d;
     }();
     return c;
@@ -332,7 +335,7 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
                 const NodeList* nodes = nullptr) {
     if (n_early) *n_early = 0;
     if (!x || !workspace || !feat_out || !npatch_out || !tlbr_out || !counts) return fail(STTM_ERR_ARG, "null pointer argument");
-    if (nodes && (nv != 1 || head_dim != 0)) return fail(STTM_ERR_UNSUPPORTED, "the stand-alone temporal stage takes one video and the whole-vector cosine");
+    if (nodes && nv != 1) return fail(STTM_ERR_UNSUPPORTED, "the stand-alone temporal stage takes one video");
     if (T < 1 || C < 1) return fail(STTM_ERR_ARG, "T and C must be positive");
     if (dtype < 0 || dtype > 2) return fail(STTM_ERR_ARG, "unknown dtype code %d", dtype);
     if (stride_c != 1) return fail(STTM_ERR_ARG, "channel stride must be 1 (channels-last view); got %lld", (long long)stride_c);
@@ -411,6 +414,9 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
     ta.pairs_var = cfg.pairs_var;
     ta.label_nt = (cfg.label_nt == 256 || cfg.label_nt == 512) ? cfg.label_nt : 1024;
     ta.temporal_thresh = temporal_thresh;
+    // the merge runs its temporal stage only for a positive threshold (quadtree_builder.py:217); cross_frame_node_merging_fast / _slow
+    // themselves filter with whatever threshold they are given (quadtree_temporal_merger.py:70-71: sim >= thresh)
+    ta.temporal_on = (temporal_thresh > 0.f || nodes) ? 1 : 0;
     ta.weighted_avg = weighted_avg ? 1 : 0;
     // slow_ver has no per-head variant upstream (cross_frame_node_merging_slow ignores head_dim)
     ta.n_head = slow_ver ? 0 : n_head; ta.head_lanes = slow_ver ? 0 : head_lanes;
@@ -441,7 +447,7 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
     sa.dev = g_dev; ta.dev = g_dev;
 #endif
 
-    const bool pairs = temporal_thresh > 0.f && T > 1;
+    const bool pairs = ta.temporal_on && T > 1;
     int fold_cap = 0;
     ta.fold_labels = (pairs && sttm::labels_can_fold(ta, nv, &fold_cap)) ? 1 : 0;
     ta.fold_cap = fold_cap;
@@ -492,6 +498,30 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
     return STTM_OK;
 }
 
+// Internal streams of the stage-skewed batch entry point: per host thread and device (two host threads may be inside
+// sttm_quadtree_merge_batch at once, each on its own caller stream; sharing the fork / join events between them would race), created
+// on first use and kept for the life of the thread (HIP may already be gone when thread-locals are destroyed at exit: never freed).
+constexpr int kSideMax = 8;
+struct SidePool { int dev; int n; hipStream_t s[kSideMax]; hipEvent_t fork; hipEvent_t join[kSideMax]; };
+SidePool* side_pool(int want) {
+    thread_local SidePool pools[4] = {};
+    thread_local int n_pools = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    if (want > kSideMax) want = kSideMax;
+    for (int i = 0; i < n_pools; ++i)
+        if (pools[i].dev == dev && pools[i].n >= want) { static thread_local SidePool view; view = pools[i]; view.n = want; return &view; }
+    if (n_pools >= 4) return nullptr;
+    SidePool p = {};
+    p.dev = dev; p.n = want;
+    if (hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+    for (int i = 0; i < want; ++i)
+        if (hipStreamCreateWithFlags(&p.s[i], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&p.join[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+    pools[n_pools] = p;
+    return &pools[n_pools++];
+}
+
 }  // namespace
 
 namespace sttm {
@@ -515,7 +545,7 @@ int sttm_configure(const char* key, int value) {
     struct { const char* name; int* slot; } keys[] = {
         {"pairs_seg", &c.pairs_seg}, {"pairs_nt", &c.pairs_nt}, {"pairs_var", &c.pairs_var}, {"k1_var", &c.k1_var}, {"k1_split", &c.k1_split}, {"no_dense", &c.no_dense}, {"gm_split", &c.gm_split}, {"label_nt", &c.label_nt},
         {"vec16", &c.vec16}, {"vec32", &c.vec32}, {"fold_kb", &c.fold_kb}, {"fold_labels", &c.fold_labels}, {"no_fuse", &c.no_fuse}, {"tome_split", &c.tome_split}, {"tome_flat", &c.tome_flat}, {"tome_rank", &c.tome_rank},
-        {"force_gmem_labels", &c.force_gmem_labels},
+        {"force_gmem_labels", &c.force_gmem_labels}, {"batch_streams", &c.batch_streams}, {"batch_sub", &c.batch_sub},
     };
     for (auto& k : keys)
         if (!strcmp(key, k.name)) { *k.slot = value; return STTM_OK; }
@@ -555,7 +585,7 @@ int sttm_quadtree_spatial(const void* x, int64_t stride_t, int64_t stride_c, int
 }
 
 int sttm_temporal_merge(const void* node_feat, const int32_t* node_tlbr, int n_nodes, int T, int C, int H, int W, int dtype,
-                        float temporal_thresh, int root_level, int weighted_avg, int slow_ver,
+                        float temporal_thresh, int root_level, int weighted_avg, int head_dim, int slow_ver,
                         void* workspace, size_t workspace_bytes, void* feat_out, int32_t* npatch_out, int32_t* tlbr_out, int32_t* counts,
                         void* stream_) {
     // cross_frame_node_merging_fast / _slow on a caller's node list (quadtree_temporal_merger.py:271-299): the nodes are brought into
@@ -564,7 +594,7 @@ int sttm_temporal_merge(const void* node_feat, const int32_t* node_tlbr, int n_n
     if (n_nodes < 0 || (int64_t)n_nodes > (int64_t)T * H * W) return fail(STTM_ERR_ARG, "n_nodes = %d outside [0, T*H*W]", n_nodes);
     const NodeList nodes{node_feat, node_tlbr, n_nodes};
     return merge_group(1, &node_feat, (int64_t)H * W * C, 1, (int64_t)W * C, C, T, C, H, W, dtype, 2.0f, temporal_thresh, root_level,
-                       weighted_avg, 0, slow_ver, workspace, workspace_bytes, &feat_out, &npatch_out, &tlbr_out, counts,
+                       weighted_avg, head_dim, slow_ver, workspace, workspace_bytes, &feat_out, &npatch_out, &tlbr_out, counts,
                        nullptr, 0, nullptr, reinterpret_cast<hipStream_t>(stream_), nullptr, nullptr, 0, nullptr, &nodes);
 }
 
@@ -603,6 +633,39 @@ int sttm_quadtree_merge_batch(int n_videos, const void* const* x, int64_t stride
     if (n_videos < 1) return fail(STTM_ERR_ARG, "n_videos must be >= 1");
     if (!x || !feat_out || !npatch_out || !tlbr_out || !counts || !workspace) return fail(STTM_ERR_ARG, "null pointer argument");
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    const Config& cfg = config();
+    // Stage-skewed form (round 5): the videos of the call are dealt out to a few internal streams, each running whole per-video
+    // chains (spatial -> pairs -> labels -> group mean) behind a fork event on the caller's stream; the caller's stream joins them
+    // at the end.  Consecutive videos are then in DIFFERENT stages at any moment -- the latency-bound label stage (16 workgroups)
+    // and the ramps / tails of one video run under the bandwidth-bound kernels of the others -- where the lockstep form below
+    // marches all videos through one kernel at a time.  Same kernels, same per-video arguments: bit-identical outputs.
+    SidePool* pool = (cfg.batch_streams >= 2 && n_videos >= 2) ? side_pool(cfg.batch_streams) : nullptr;
+    if (pool) {
+        const int S = pool->n < n_videos ? pool->n : n_videos;
+        const int sub = cfg.batch_sub < 1 ? 1 : (cfg.batch_sub > STTM_BATCH_MAX ? STTM_BATCH_MAX : cfg.batch_sub);
+        mark(events, 0, stream);
+        hipError_t e = hipEventRecord(pool->fork, stream);
+        for (int i = 0; i < S && e == hipSuccess; ++i) e = hipStreamWaitEvent(pool->s[i], pool->fork, 0);
+        if (e != hipSuccess) return fail(STTM_ERR_LAUNCH, "batch fork: %s", hipGetErrorString(e));
+        int rc = STTM_OK, lane = 0;
+        for (int v0 = 0; v0 < n_videos && rc == STTM_OK; v0 += sub, lane = (lane + 1) % S) {
+            const int nv = n_videos - v0 < sub ? n_videos - v0 : sub;
+            rc = merge_group(nv, x + v0, stride_t, stride_c, stride_h, stride_w, T, C, H, W, dtype, threshold, temporal_thresh,
+                             root_level, weighted_avg, head_dim, slow_ver,
+                             reinterpret_cast<char*>(workspace) + (size_t)v0 * workspace_stride, workspace_stride,
+                             feat_out + v0, npatch_out + v0, tlbr_out + v0, counts + (size_t)v0 * STTM_CNT_SLOTS,
+                             counts_host ? counts_host + (size_t)v0 * STTM_CNT_SLOTS : nullptr, seq + v0,
+                             nullptr, pool->s[lane], nullptr, nullptr, flags);
+        }
+        // join even after a failed launch: whatever was enqueued on the internal streams stays ordered before the caller's next work
+        for (int i = 0; i < S; ++i) {
+            hipError_t j = hipEventRecord(pool->join[i], pool->s[i]);
+            if (j == hipSuccess) j = hipStreamWaitEvent(stream, pool->join[i], 0);
+            if (j != hipSuccess && rc == STTM_OK) rc = fail(STTM_ERR_LAUNCH, "batch join: %s", hipGetErrorString(j));
+        }
+        for (int i = 1; i < STTM_EVENT_SLOTS; ++i) mark(events, i, stream);
+        return rc;
+    }
     for (int v0 = 0; v0 < n_videos; v0 += STTM_BATCH_MAX) {
         const int nv = n_videos - v0 < STTM_BATCH_MAX ? n_videos - v0 : STTM_BATCH_MAX;
         // the caller's events bracket the whole call: the start comes from the first group, the rest from the last

@@ -96,7 +96,9 @@ struct TemporalArgs {
     int T, H, W, C, R;        // R = root cells per frame
     LevelDims dims;
     int dtype, vec;
-    float temporal_thresh;    // <= 0: no edges (labels stay the identity)
+    float temporal_thresh;    // cosine threshold of the pair filter
+    int temporal_on;          // 0: no temporal stage (labels stay the identity).  The merge: temporal_thresh > 0 (quadtree_builder.py:217);
+                              // the stand-alone temporal stage: always (cross_frame_node_merging_fast filters with whatever threshold it is given)
     int n_head, head_lanes;   // per-head cosine in the pair filter (0 = whole vector)
     int inline_norms;         // the pair kernel computes |x| itself (spatial stage ran per-head, pair filter does not)
     int slow_ver;

@@ -311,7 +311,7 @@ __device__ __forceinline__ bool column_labels(const TemporalArgs& a, int r, cons
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nwave = nt >> 6;
     const int slots = col.slots, W = (slots + 31) >> 5;
-    const bool temporal = a.temporal_thresh > 0.f && a.T > 1;
+    const bool temporal = a.temporal_on && a.T > 1;
     int* rep = arr.rep; int* rep2 = arr.rep2; int* cslot = arr.cslot; int* edges = arr.edges;
     int* bits = arr.bits; int* wpre = arr.wpre; int* dec = arr.dec;
     int* rawd = arr.rep; int* raws = arr.rep2;
@@ -645,7 +645,7 @@ __device__ __forceinline__ bool column_labels_dense(const TemporalArgs& a, int r
     const int lane = tid & 63, nwave = nt >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int slots = col.slots, W = (slots + 31) >> 5;
-    const bool temporal = a.temporal_thresh > 0.f && a.T > 1;
+    const bool temporal = a.temporal_on && a.T > 1;
     int* L = arr.rep; int* Sa = arr.rep2; int* Sb = arr.cslot; int* edges = arr.edges;
     int* bits = arr.bits; int* dec = arr.dec;
     const int nf = a.T - 1;
@@ -1108,7 +1108,7 @@ void pairs_shape(int T, int R, int fold, int want_seg, int want_nt, int* seg, in
 // in-kernel grid barrier occupy at most half of the CUs (a 1024-thread workgroup can take a CU for itself), so every other
 // workgroup of the launch still finds a CU and runs to completion.
 bool labels_can_fold(const TemporalArgs& a, int n_videos, int* cap) {
-    if (!a.want_fold || a.slow_ver || !(a.temporal_thresh > 0.f) || a.T < 2) return false;
+    if (!a.want_fold || a.slow_ver || !a.temporal_on || a.T < 2) return false;
     const int cus = device_cus();
     if (cus <= 0 || (long long)a.R * n_videos > cus / 2) return false;
     // ... and the whole pair grid runs in ONE round (a workgroup of 512+ threads has a CU to itself): grids of several
@@ -1235,7 +1235,7 @@ hipError_t launch_col_labels(const TemporalArgs& a, const BatchPtrs& bp, int n_v
     const int nthreads = col_threads(a);
     const size_t smem = col_lds_bytes(cap, cap > 0 ? a.max_slots : 0, cap > 0 ? a.T : 0);
     if (probe) {
-        if (!(a.temporal_thresh > 0.f && a.T > 1)) return hipSuccess;
+        if (!(a.temporal_on && a.T > 1)) return hipSuccess;
         hipLaunchKernelGGL((k_col_labels<COL_PROBE>), dim3(a.R, n_videos), dim3(nthreads), smem, stream, a, bp, cap);
     } else {
         hipLaunchKernelGGL((k_col_labels<COL_FINAL>), dim3(a.R, n_videos), dim3(nthreads), smem, stream, a, bp, cap);
@@ -1737,20 +1737,75 @@ __global__ void __launch_bounds__(256, OCC) k_group_mean(const TemporalArgs a0, 
 // (frame, root cell), the geometry table, zeroed counters -- and the pair, label and group-mean kernels run unchanged.
 // One workgroup per node copies the row and sums its squares on the way (fp32 per lane, fixed-order tree over the lanes and waves).
 // ---------------------------------------------------------------------------------------------------
+// true iff [y1, y2) x [x1, x2) is the leaf extent of ONE cell of the pyramid `g` (any level from the root level down): walk up from
+// the origin leaf and compare the extent of every ancestor
+__device__ __forceinline__ bool box_is_tree_cell(const LevelDims& g, int y1, int x1, int y2, int x2) {
+    int i = y1, j = x1;
+    for (int l = g.n_level - 1; l >= 0; --l) {
+        int lo_i = i, hi_i = i, lo_j = j, hi_j = j;
+        for (int m = l; m < g.n_level - 1; ++m) {
+            lo_i = child_start(lo_i, g.h[m + 1]);
+            hi_i = child_start(hi_i, g.h[m + 1]) + child_count(hi_i, g.h[m + 1]) - 1;
+            lo_j = child_start(lo_j, g.w[m + 1]);
+            hi_j = child_start(hi_j, g.w[m + 1]) + child_count(hi_j, g.w[m + 1]) - 1;
+        }
+        if (lo_i == y1 && lo_j == x1 && hi_i + 1 == y2 && hi_j + 1 == x2) return true;
+        if (lo_i != y1 || lo_j != x1) return false;          // a coarser ancestor no longer starts at this leaf
+        if (l > 0) { i = parent_of(i, g.h[l]); j = parent_of(j, g.w[l]); }
+    }
+    return false;
+}
+
+// One workgroup per node of the caller's list.  A node is taken only if (a) its box lies inside the grid, (b) the box is a cell of the
+// root_level partition (what quadtree_build_video emits), (c) none of its leaves is covered by another node of the list -- every node
+// marks its leaves in `cover` with atomic adds, so duplicated origins and overlapping boxes are seen by at least one of the two nodes --
+// and (d) its root cell's list has room.  A rejected node writes nothing but the sticky overflow flag (bar[1] -> counts[STTM_CNT_OVERFLOW],
+// "outputs invalid"); the tables the later kernels walk stay consistent (list heads count stored entries only, one node per origin,
+// disjoint boxes), so those kernels stay inside their buffers whatever the caller passed.
 template <typename T>
 __global__ void __launch_bounds__(256) k_ingest_nodes(const TemporalArgs a, const void* feat, const int32_t* tlbr, int n_nodes,
-                                                      void* S, uint32_t* meta, double* inrm, int* rc_list) {
+                                                      void* S, uint32_t* meta, double* inrm, int* rc_list, int32_t* cover) {
     __shared__ float wsum[4];
+    __shared__ int bad;
     const int i = blockIdx.x;
     if (i >= n_nodes) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = tlbr[5 * i], y1 = tlbr[5 * i + 1], x1 = tlbr[5 * i + 2], y2 = tlbr[5 * i + 3], x2 = tlbr[5 * i + 4];
-    const bool ok = t >= 0 && t < a.T && y1 >= 0 && x1 >= 0 && y2 > y1 && x2 > x1 && y2 <= a.H && x2 <= a.W;
-    if (!ok) {                          // (uniform) a box outside the grid: the call reports an overflow, nothing is written
+    const bool ok = t >= 0 && t < a.T && y1 >= 0 && x1 >= 0 && y2 > y1 && x2 > x1 && y2 <= a.H && x2 <= a.W &&
+                    box_is_tree_cell(a.dims, y1, x1, y2, x2);
+    if (!ok) {                          // (uniform) not a cell of the partition: the call reports an overflow, nothing is written
+        if (tid == 0) __hip_atomic_fetch_or(a.bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    if (tid == 0) bad = 0;
+    __syncthreads();
+    const int bw = x2 - x1, area = (y2 - y1) * bw;
+    for (int q = tid; q < area; q += 256) {
+        const int ly = q / bw, lx = q - ly * bw;
+        if (atomicAdd(cover + (int64_t)t * a.H * a.W + (y1 + ly) * a.W + (x1 + lx), 1) != 0) bad = 1;
+    }
+    __syncthreads();
+    if (bad) {                          // (uniform) a duplicated origin or an overlapping box
         if (tid == 0) __hip_atomic_fetch_or(a.bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     const int64_t row = (int64_t)t * a.H * a.W + y1 * a.W + x1;
+    const int rcell = root_cell_of(a.dims, y1, x1);
+    int* list = rc_list + ((int64_t)t * a.R + rcell) * a.rc_stride;
+    const bool one = y2 - y1 == 1 && x2 - x1 == 1;
+    if (tid == 0) {
+        // the list head counts STORED entries only: an entry that finds the list full takes its increment back (no node is
+        // ever stored at or beyond rc_stride - 1, and the later kernels never read a count above it)
+        const int inc = 1 + (one ? 1 << 16 : 0);
+        const int pos = atomicAdd(list, inc) & 0xffff;
+        if (pos < a.rc_stride - 1) list[1 + pos] = (y1 << 24) | (x1 << 16) | (y2 << 8) | x2;
+        else { atomicSub(list, inc); bad = 1; }
+    }
+    __syncthreads();
+    if (bad) {                          // more nodes than leaves in a root cell
+        if (tid == 0) __hip_atomic_fetch_or(a.bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     float acc = 0.f;
     for (int c = tid; c < a.C; c += 256) {
         float v;
@@ -1774,13 +1829,6 @@ __global__ void __launch_bounds__(256) k_ingest_nodes(const TemporalArgs a, cons
         inrm[row] = 1.0 / (sqrt((double)n2) + 1e-8);
         a.lab_row[row] = (int32_t)row;
         a.gcnt[row] = 1;
-        const int rcell = root_cell_of(a.dims, y1, x1);
-        int* list = rc_list + ((int64_t)t * a.R + rcell) * a.rc_stride;
-        const bool one = y2 - y1 == 1 && x2 - x1 == 1;
-        const int old = atomicAdd(list, 1 + (one ? 1 << 16 : 0));
-        const int pos = old & 0xffff;
-        if (pos < a.rc_stride - 1) list[1 + pos] = (y1 << 24) | (x1 << 16) | (y2 << 8) | x2;
-        else __hip_atomic_fetch_or(a.bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // more nodes than leaves in a root cell
     }
 }
 // geometry table + the counters the spatial kernel zeroes
@@ -1806,14 +1854,17 @@ hipError_t launch_ingest_nodes(const TemporalArgs& a, const void* feat, const in
     if ((e = hipMemsetAsync(a.lab_row, 0xff, N * 4, stream)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(rc_list, 0, (size_t)a.T * a.R * a.rc_stride * 4, stream)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(a.bar, 0, 32, stream)) != hipSuccess) return e;
+    // leaf cover marks of the ingest (the label scratch is >= 10 N ints and is written by the label stage before it reads it)
+    int32_t* cover = a.colscratch;
+    if ((e = hipMemsetAsync(cover, 0, N * 4, stream)) != hipSuccess) return e;
     int most = a.H * a.W;
     if (a.T > most) most = a.T;
     if (a.R > most) most = a.R;
     hipLaunchKernelGGL(k_ingest_geo, dim3((most + 255) / 256), dim3(256), 0, stream, a, cgeo);
     if (n_nodes > 0) {
-        if (a.dtype == STTM_F32) hipLaunchKernelGGL((k_ingest_nodes<float>), dim3(n_nodes), dim3(256), 0, stream, a, feat, tlbr, n_nodes, S, meta, inrm, rc_list);
-        else if (a.dtype == STTM_BF16) hipLaunchKernelGGL((k_ingest_nodes<bf16_t>), dim3(n_nodes), dim3(256), 0, stream, a, feat, tlbr, n_nodes, S, meta, inrm, rc_list);
-        else hipLaunchKernelGGL((k_ingest_nodes<f16_t>), dim3(n_nodes), dim3(256), 0, stream, a, feat, tlbr, n_nodes, S, meta, inrm, rc_list);
+        if (a.dtype == STTM_F32) hipLaunchKernelGGL((k_ingest_nodes<float>), dim3(n_nodes), dim3(256), 0, stream, a, feat, tlbr, n_nodes, S, meta, inrm, rc_list, cover);
+        else if (a.dtype == STTM_BF16) hipLaunchKernelGGL((k_ingest_nodes<bf16_t>), dim3(n_nodes), dim3(256), 0, stream, a, feat, tlbr, n_nodes, S, meta, inrm, rc_list, cover);
+        else hipLaunchKernelGGL((k_ingest_nodes<f16_t>), dim3(n_nodes), dim3(256), 0, stream, a, feat, tlbr, n_nodes, S, meta, inrm, rc_list, cover);
     }
     return hipGetLastError();
 }

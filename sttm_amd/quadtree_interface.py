@@ -555,21 +555,15 @@ def get_quadtree_features_into(dest, _video_feature, threshold, temporal_thresh=
 get_quadtree_features_into.returns_idx = True        # patch_hooks._merge_concat asks for merged_token_1d_idx along with the merge
 
 
-def cross_frame_node_merging_fast(quadtree_features_video, quadtree_tyxyx_tlbr, temporal_thresh, quadtree_num_patches_per_node=None,
-                                  weighted_avg=False, head_dim=None, *, grid, root_level, slow_ver=False):
-    """The temporal stage alone on a node list (reference: `cross_frame_node_merging_fast` / `_slow`,
-    token_merging_utils/quadtree_temporal_merger.py:271-299; C ABI: `sttm_temporal_merge`).
+def temporal_merge_nodes(node_features, node_tlbr, temporal_thresh, weighted_avg=False, head_dim=None, *, grid, root_level, slow_ver=False):
+    """Extension: the temporal stage alone on a node list in ANY order (C ABI: `sttm_temporal_merge`).
 
-    quadtree_features_video [N, C] (float32 / bfloat16 / float16) and quadtree_tyxyx_tlbr [N, 5] = (t, y1, x1, y2, x2) are the
-    nodes the spatial stage emits (`get_quadtree_features(..., temporal_thresh=-1)`); `grid = (T, H, W)` and `root_level` name the
-    quadtree partition they come from (the reference function derives neither: it compares every pair of boxes; here the nodes go
-    into the per-root-cell tables of the fused merge, so every box must be a cell of that partition).  `quadtree_num_patches_per_node`
-    is accepted for signature compatibility: the patch counts are the box areas.  Returns (features [N', C], num_patches [N'],
-    tlbr [N', 5]) ordered by (t, y1, x1), like `agg_feature_and_metadata`."""
-    if head_dim is not None:
-        raise NotImplementedError("the stand-alone temporal stage uses the whole-vector cosine (head_dim=None); "
-                                  "get_quadtree_features(..., head_dim=...) runs the per-head variant inside the merge")
-    x, tl = quadtree_features_video, quadtree_tyxyx_tlbr
+    node_features [N, C] (float32 / bfloat16 / float16) and node_tlbr [N, 5] = (t, y1, x1, y2, x2) are nodes of the quadtree partition
+    `grid = (T, H, W)` / `root_level` (what `get_quadtree_features(..., temporal_thresh=-1)` emits; every box must be a cell of that
+    partition and the boxes of a frame must be disjoint -- anything else raises).  Returns (features [N', C], num_patches [N'] = box
+    areas summed over each group, tlbr [N', 5]) ordered by (t, y1, x1); a group is represented by its first node in that order.  The
+    pair filter keeps `sim >= temporal_thresh` for any sign of the threshold, like quadtree_temporal_merger.py:70-71."""
+    x, tl = node_features, node_tlbr
     if not x.is_cuda:
         raise RuntimeError("sttm_amd runs on the GPU only: the input must be a CUDA (ROCm) tensor; there is no CPU fallback")
     if x.dtype not in _DTYPE_CODE:
@@ -578,6 +572,7 @@ def cross_frame_node_merging_fast(quadtree_features_video, quadtree_tyxyx_tlbr, 
     N, C = x.shape
     if tl.shape != (N, 5):
         raise ValueError(f"tlbr must be [N, 5]; got {tuple(tl.shape)} for N = {N}")
+    head = 0 if head_dim is None else int(head_dim)
     lib = _lib.load()
     dev = x.device
     x = x.contiguous()
@@ -594,20 +589,61 @@ def cross_frame_node_merging_fast(quadtree_features_video, quadtree_tyxyx_tlbr, 
         tlbr = torch.empty((rows, 5), dtype=torch.int32, device=dev)
         counts = torch.zeros(_lib.CNT_SLOTS, dtype=torch.int32, device=dev)
         rc = lib.sttm_temporal_merge(x.data_ptr(), tl.data_ptr(), N, T, C, H, W, code, float(temporal_thresh), int(root_level),
-                                     1 if weighted_avg else 0, 1 if slow_ver else 0, ws.data_ptr(), nbytes,
+                                     1 if weighted_avg else 0, head, 1 if slow_ver else 0, ws.data_ptr(), nbytes,
                                      feat.data_ptr(), npatch.data_ptr(), tlbr.data_ptr(), counts.data_ptr(),
                                      torch.cuda.current_stream(dev).cuda_stream)
         _lib.raise_for(rc)
         cnt = counts.cpu().tolist()
     if cnt[_lib.CNT_OVERFLOW]:
-        raise RuntimeError(f"sttm_temporal_merge: invalid node list (overflow flags {cnt[_lib.CNT_OVERFLOW]}): boxes outside the "
-                           f"{H} x {W} grid, or nodes that are not cells of the root_level = {root_level} partition")
+        raise RuntimeError(f"sttm_temporal_merge: invalid node list (overflow flags {cnt[_lib.CNT_OVERFLOW]}): a box outside the "
+                           f"{H} x {W} grid, a box that is not a cell of the root_level = {root_level} partition, a duplicated origin, "
+                           "overlapping boxes, or more nodes than leaves in a root cell")
     n = cnt[_lib.CNT_OUT]
     return feat[:n], npatch[:n], tlbr[:n]
 
 
-def cross_frame_node_merging_slow(quadtree_features_video, quadtree_tyxyx_tlbr, temporal_thresh, quadtree_num_patches_per_node=None,
-                                  weighted_avg=False, head_dim=None, *, grid, root_level):
-    """`cross_frame_node_merging_slow` (quadtree_temporal_merger.py:289-299): the similarity-sorted pair filter."""
-    return cross_frame_node_merging_fast(quadtree_features_video, quadtree_tyxyx_tlbr, temporal_thresh, quadtree_num_patches_per_node,
-                                         weighted_avg, head_dim, grid=grid, root_level=root_level, slow_ver=True)
+def _merging_as_the_reference(x, tl, temporal_thresh, num_patches, weighted_avg, head_dim, cos, sin, grid, root_level, slow_ver):
+    if cos is not None or sin is not None:
+        raise NotImplementedError("position embeddings ride along the fused merge only (get_quadtree_features(..., pos_embs=...))")
+    if grid is None or root_level is None:
+        raise TypeError("sttm_amd needs grid=(T, H, W) and root_level=... (keyword arguments): the nodes go into the per-root-cell "
+                        "tables of the fused merge, which the reference function -- comparing every pair of boxes -- does not need")
+    tl = tl.to(device=x.device)
+    # the reference's representative is the LOWEST INDEX of a group and its output keeps the input order: that equals this
+    # implementation's (t, y1, x1) order exactly when the list is sorted that way, as quadtree_build_video passes it
+    # (quadtree_builder.py:198-203)
+    if tl.shape[0] > 1:
+        T, H, W = (int(v) for v in grid)
+        key = (tl[:, 0].long() * H + tl[:, 1].long()) * W + tl[:, 2].long()
+        if not bool((key[1:] > key[:-1]).all()):
+            raise ValueError("the node list must be sorted by (t, y1, x1) without duplicates, as quadtree_build_video passes it "
+                             "(temporal_merge_nodes takes any order and represents a group by its first node in that order)")
+    if num_patches is not None:
+        area = (tl[:, 3] - tl[:, 1]) * (tl[:, 4] - tl[:, 2])
+        if not torch.equal(num_patches.to(device=x.device, dtype=area.dtype), area):
+            raise NotImplementedError("quadtree_num_patches_per_node must equal the box areas (what quadtree_build_video passes, "
+                                      "quadtree_builder.py:206-209): the kernels derive the patch counts from the boxes")
+    feat, npatch, tlbr = temporal_merge_nodes(x, tl, temporal_thresh, weighted_avg, head_dim, grid=grid, root_level=root_level,
+                                              slow_ver=slow_ver)
+    return {"feature": feat, "num_patch": npatch, "tlbr": tlbr}
+
+
+def cross_frame_node_merging_fast(quadtree_features_video, quadtree_tyxyx_tlbr, temporal_thresh, quadtree_num_patches_per_node,
+                                  weighted_avg=False, head_dim=None, quadtree_pos_embs_cos=None, quadtree_pos_embs_sin=None,
+                                  pos_emb_weighted_avg=False, *, grid=None, root_level=None):
+    """`cross_frame_node_merging_fast` of the reference (token_merging_utils/quadtree_temporal_merger.py:271-287): same positional
+    arguments, same return value -- the dict {'feature', 'num_patch', 'tlbr'} of agg_feature_and_metadata (:147-151) -- on the GPU.
+    Two keyword arguments are added: `grid = (T, H, W)` and `root_level`, the quadtree partition the nodes come from.
+    Differences a caller can meet, each raised instead of answered differently: the list must be sorted by (t, y1, x1) (ValueError),
+    `quadtree_num_patches_per_node` must be the box areas (NotImplementedError), no position embeddings here (NotImplementedError)."""
+    return _merging_as_the_reference(quadtree_features_video, quadtree_tyxyx_tlbr, temporal_thresh, quadtree_num_patches_per_node,
+                                     weighted_avg, head_dim, quadtree_pos_embs_cos, quadtree_pos_embs_sin, grid, root_level, False)
+
+
+def cross_frame_node_merging_slow(quadtree_features_video, quadtree_tyxyx_tlbr, temporal_thresh, quadtree_num_patches_per_node,
+                                  weighted_avg=False, head_dim=None, quadtree_pos_embs_cos=None, quadtree_pos_embs_sin=None,
+                                  pos_emb_weighted_avg=False, *, grid=None, root_level=None):
+    """`cross_frame_node_merging_slow` (quadtree_temporal_merger.py:289-299): the similarity-sorted pair filter; `head_dim` is ignored
+    like the reference ignores it (:293)."""
+    return _merging_as_the_reference(quadtree_features_video, quadtree_tyxyx_tlbr, temporal_thresh, quadtree_num_patches_per_node,
+                                     weighted_avg, None, quadtree_pos_embs_cos, quadtree_pos_embs_sin, grid, root_level, True)

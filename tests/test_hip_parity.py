@@ -430,14 +430,18 @@ def test_stand_alone_spatial_entry_point():
 
 
 TEMPORAL_ONLY_CASES = [
-    # (T, C, H, W, seed, dtype, threshold of the spatial stage that makes the node list, temporal, root_level, weighted, slow)
-    (8, 1024, 14, 14, 60, torch.float32, 0.85, 0.55, 1, False, False),
-    (6, 256, 14, 14, 61, torch.float32, 0.80, 0.50, 1, True, False),
-    (6, 256, 14, 14, 62, torch.float32, 0.85, 0.55, 1, False, True),       # cross_frame_node_merging_slow
-    (5, 128, 20, 36, 63, torch.bfloat16, 0.85, 0.60, 1, False, False),     # 4-level partition
-    (4, 96, 27, 27, 64, torch.float16, 0.80, 0.50, 0, False, False),       # 5-level partition
-    (5, 64, 14, 14, 65, torch.float32, 0.85, -1.0, 1, False, False),       # no merging: the nodes come back in order
-    (64, 1024, 14, 14, 66, torch.float32, 0.85, 0.65, 1, False, False),    # BASELINE config 2 size
+    # (T, C, H, W, seed, dtype, threshold of the spatial stage that makes the node list, temporal, root_level, weighted, slow, head_dim)
+    (8, 1024, 14, 14, 60, torch.float32, 0.85, 0.55, 1, False, False, None),
+    (6, 256, 14, 14, 61, torch.float32, 0.80, 0.50, 1, True, False, None),
+    (6, 256, 14, 14, 62, torch.float32, 0.85, 0.55, 1, False, True, None),       # cross_frame_node_merging_slow
+    (5, 128, 20, 36, 63, torch.bfloat16, 0.85, 0.60, 1, False, False, None),     # 4-level partition
+    (4, 96, 27, 27, 64, torch.float16, 0.80, 0.50, 0, False, False, None),       # 5-level partition
+    (5, 64, 14, 14, 65, torch.float32, 0.85, -1.0, 1, False, False, None),       # threshold <= 0: the function itself still filters with it (:70-71)
+    (5, 64, 14, 14, 67, torch.float32, 0.85, -0.05, 1, True, False, None),       # ... weighted: unmerged nodes are divided by their areas too (:142-143)
+    (64, 1024, 14, 14, 66, torch.float32, 0.85, 0.65, 1, False, False, None),    # BASELINE config 2 size
+    (6, 256, 14, 14, 68, torch.float32, 0.85, 0.55, 1, False, False, 64),        # per-head cosine (quadtree_temporal_merger.py:65-68; ABI v7)
+    (5, 512, 14, 14, 69, torch.bfloat16, 0.85, 0.55, 1, False, False, 128),
+    (6, 256, 14, 14, 70, torch.float32, 0.85, 0.55, 1, False, True, 64),         # slow_ver ignores head_dim (:293)
 ]
 
 
@@ -445,37 +449,77 @@ TEMPORAL_ONLY_CASES = [
 def test_stand_alone_temporal_stage_on_a_node_list(case):
     """`cross_frame_node_merging_fast` / `_slow` on a caller's node list (quadtree_temporal_merger.py:271-299; C ABI
     `sttm_temporal_merge`): the node list is the ORACLE's spatial stage, the expectation the oracle's `temporal_merge` on it -- and
-    the result equals the fused merge of the same video."""
+    the result equals the fused merge of the same video.  Same call, same dict as the reference's function."""
     from oracle import sttm_oracle as O
     from sttm_amd import get_quadtree_features
-    from sttm_amd.quadtree_interface import cross_frame_node_merging_fast, cross_frame_node_merging_slow
+    from sttm_amd.quadtree_interface import cross_frame_node_merging_fast, cross_frame_node_merging_slow, temporal_merge_nodes
     from sttm_amd.synth import synth_video
-    T, C, H, W, seed, dtype, thr, tthr, root, weighted, slow = case
+    T, C, H, W, seed, dtype, thr, tthr, root, weighted, slow, head = case
     x = synth_video(T, C, H, W, seed=seed, dtype=dtype)
     nf, nn, nt = O.get_quadtree_features(x, thr, -1.0, root, weighted)                    # the node list
-    exp = O.temporal_merge(nf, nt, nn, tthr, weighted, None, slow) if tthr > 0 else (nf, nn, nt)
+    if weighted:
+        # (the builder divides by the patch counts only AFTER the temporal stage: hand the stage the undivided sums it would see)
+        nf = (nf.float() * nn.unsqueeze(-1)).to(dtype)
+    exp = O.temporal_merge(nf, nt, nn, tthr, weighted, None if slow else head, slow)
     fn = cross_frame_node_merging_slow if slow else cross_frame_node_merging_fast
-    out = fn(nf.to(_dev()), nt.to(_dev()), tthr, nn.to(_dev()), weighted, None, grid=(T, H, W), root_level=root)
+    res = fn(nf.to(_dev()), nt.to(_dev()), tthr, nn.to(_dev()), weighted, head, grid=(T, H, W), root_level=root)
+    assert sorted(res) == ["feature", "num_patch", "tlbr"]
+    out = (res["feature"], res["num_patch"], res["tlbr"])
     tol = FP32_TOL if dtype == torch.float32 else BF16_TOL
     _check(out, exp[:3], tol, "stand-alone temporal stage")
-    if tthr > 0:
-        fused = get_quadtree_features(x.to(_dev()), thr, tthr, root, weighted, slow_ver=slow)
-        assert torch.equal(out[2], fused[2]) and torch.equal(out[1], fused[1])
-    # a shuffled node list gives the same result (origins, not list positions, order the nodes)
+    if tthr > 0 and not weighted:
+        fused = get_quadtree_features(x.to(_dev()), thr, tthr, root, weighted, slow_ver=slow, head_dim=None if slow else head)
+        if head is None or slow:          # (with head_dim the fused call's SPATIAL stage is per-head too: a different node list)
+            assert torch.equal(out[2], fused[2]) and torch.equal(out[1], fused[1])
+    # the extension takes the list in any order (origins, not list positions, order the nodes)
     perm = torch.randperm(nf.shape[0], generator=torch.Generator().manual_seed(seed))
-    out2 = fn(nf[perm].to(_dev()), nt[perm].to(_dev()), tthr, None, weighted, None, grid=(T, H, W), root_level=root)
+    out2 = temporal_merge_nodes(nf[perm].to(_dev()), nt[perm].to(_dev()), tthr, weighted, None if slow else head, grid=(T, H, W),
+                                root_level=root, slow_ver=slow)
     for a, b in zip(out, out2):
         assert torch.equal(a, b)
 
 
-def test_stand_alone_temporal_stage_rejects_boxes_outside_the_grid():
-    from sttm_amd.quadtree_interface import cross_frame_node_merging_fast
+def test_stand_alone_temporal_stage_rejects_what_it_cannot_answer_like_the_reference():
+    from sttm_amd.quadtree_interface import cross_frame_node_merging_fast, temporal_merge_nodes
     feat = torch.randn(3, 64, device=_dev())
     tl = torch.tensor([[0, 0, 0, 1, 1], [0, 0, 1, 1, 2], [1, 13, 13, 15, 15]], dtype=torch.int32, device=_dev())
-    with pytest.raises(RuntimeError, match="invalid node list"):
+    with pytest.raises(RuntimeError, match="invalid node list"):                          # a box outside the grid
         cross_frame_node_merging_fast(feat, tl, 0.5, None, grid=(2, 14, 14), root_level=1)
-    with pytest.raises(NotImplementedError):
-        cross_frame_node_merging_fast(feat, tl, 0.5, None, False, 32, grid=(2, 14, 14), root_level=1)
+    ok = torch.tensor([[0, 0, 0, 1, 1], [0, 0, 1, 1, 2], [1, 0, 0, 2, 2]], dtype=torch.int32, device=_dev())
+    with pytest.raises(ValueError, match="sorted"):                                        # the reference's order-dependent representative
+        cross_frame_node_merging_fast(feat, ok[[1, 0, 2]], 0.5, None, grid=(2, 14, 14), root_level=1)
+    with pytest.raises(NotImplementedError, match="box areas"):
+        cross_frame_node_merging_fast(feat, ok, 0.5, torch.tensor([1, 1, 3]), grid=(2, 14, 14), root_level=1)
+    with pytest.raises(TypeError, match="grid"):
+        cross_frame_node_merging_fast(feat, ok, 0.5, None)
+    res = cross_frame_node_merging_fast(feat, ok, 0.5, torch.tensor([1, 1, 4]), grid=(2, 14, 14), root_level=1)
+    assert res["tlbr"].shape[1] == 5 and 1 <= res["feature"].shape[0] <= 3
+    # node lists that are not a set of disjoint cells of the partition: every kind is reported, none crashes or corrupts memory
+    bad_lists = {
+        "not a cell": [[0, 0, 0, 1, 1], [0, 1, 1, 3, 3]],                                 # 2x2 box that straddles two mids
+        "duplicated origin": [[0, 0, 0, 1, 1], [0, 0, 0, 1, 1]],
+        "overlap": [[0, 2, 2, 6, 6], [0, 2, 2, 4, 4]],                                     # a root cell and one of its mids
+        "over-full root cell": [[0, 2 + (k // 4), 2 + (k % 4), 3 + (k // 4), 3 + (k % 4)] for k in range(16)] + [[0, 2, 2, 4, 4]],
+    }
+    for what, boxes in bad_lists.items():
+        tlb = torch.tensor(boxes, dtype=torch.int32, device=_dev())
+        f = torch.randn(len(boxes), 64, device=_dev())
+        with pytest.raises(RuntimeError, match="invalid node list"):
+            temporal_merge_nodes(f, tlb, 0.5, grid=(2, 14, 14), root_level=1)
+    torch.cuda.synchronize()
+    # 300 random garbage lists (random boxes inside the grid, many of them no cells, many overlapping): must raise or answer, never fault
+    g = torch.Generator().manual_seed(5)
+    for it in range(300):
+        n = int(torch.randint(1, 40, (1,), generator=g))
+        y1 = torch.randint(0, 14, (n,), generator=g); x1 = torch.randint(0, 14, (n,), generator=g)
+        hh = torch.randint(1, 5, (n,), generator=g); ww = torch.randint(1, 5, (n,), generator=g)
+        tlb = torch.stack([torch.randint(0, 2, (n,), generator=g), y1, x1, torch.minimum(y1 + hh, torch.tensor(14)),
+                           torch.minimum(x1 + ww, torch.tensor(14))], 1).to(torch.int32).to(_dev())
+        try:
+            temporal_merge_nodes(torch.randn(n, 64, device=_dev()), tlb, 0.3, grid=(2, 14, 14), root_level=1)
+        except RuntimeError as e:
+            assert "invalid node list" in str(e)
+    torch.cuda.synchronize()
 
 
 def test_stand_alone_temporal_stage_through_the_c_abi_error_codes():
@@ -492,7 +536,7 @@ def test_stand_alone_temporal_stage_through_the_c_abi_error_codes():
     stream = torch.cuda.current_stream().cuda_stream
 
     def call(n_nodes, feat_ptr=feat.data_ptr(), ws_bytes=nbytes, root=1):
-        return lib.sttm_temporal_merge(feat_ptr, tl.data_ptr(), n_nodes, T, C, H, W, 0, 0.5, root, 0, 0, ws.data_ptr(), ws_bytes,
+        return lib.sttm_temporal_merge(feat_ptr, tl.data_ptr(), n_nodes, T, C, H, W, 0, 0.5, root, 0, 0, 0, ws.data_ptr(), ws_bytes,
                                        out.data_ptr(), npatch.data_ptr(), tlbr.data_ptr(), counts.data_ptr(), stream)
     assert call(4) == 0
     torch.cuda.synchronize()
