@@ -176,6 +176,43 @@ def run_configs(dev, rank, world, timed, log):
                     "frac_of_copy_rate": round(B * vps / 1e9 / HBM_COPY_GBS, 4)})
         log(f"config {name}: {vps:.1f} videos/s, frac {out[-1]['frac']}")
         del pool
+    # the step before the path: the merge starting from the UNPOOLED projector tokens [T, 729, C] bf16 (27 x 27 per frame,
+    # llava/eval/video_feat_llavavideo.py:89-95 behind the projector): get_2dPool fused into the spatial kernel's leaf load against the
+    # two-step form (sttm_pool2d writes the 14 x 14 map, the merge reads it back).  B = read every SOURCE token once + write every merged token.
+    from sttm_amd import get_quadtree_features_from_pooled_input
+    from sttm_amd.upstream import get_2dPool
+    T, C, side = 128, 3584, 27
+    npool = 3
+    g = torch.Generator(device=dev).manual_seed(4242 + rank)
+    src = []
+    for i in range(npool):
+        v = synth_video(T, C, 14, 14, seed=7300 + i, dtype=torch.bfloat16, device=dev, gen_device=dev)      # [T, C, 14, 14] view of [T, 14, 14, C]
+        up = torch.nn.functional.interpolate(v.float(), size=(side, side), mode="bilinear").to(torch.bfloat16)
+        src.append((up + 0.02 * torch.randn(up.shape, device=dev, generator=g).to(torch.bfloat16)).permute(0, 2, 3, 1).reshape(T, side * side, C).contiguous())
+        del v, up
+    kept = [get_quadtree_features_from_pooled_input(x, 0.85, 0.55, 1)[0].shape[0] for x in src]
+    reps = 24
+
+    def run_fused():
+        for i in range(reps):
+            get_quadtree_features_from_pooled_input(src[i % npool], 0.85, 0.55, 1)
+
+    def run_two_step():
+        for i in range(reps):
+            pooled = get_2dPool(src[i % npool], stride=2, mode="bilinear")
+            get_quadtree_features(pooled.reshape(T, 14, 14, C).permute(0, 3, 1, 2), 0.85, 0.55, 1)
+    run_two_step()
+    vps_f, vps_2 = timed(run_fused, reps) / world, timed(run_two_step, reps) / world
+    n_out = sum(kept) / len(kept)
+    B = 2 * C * T * side * side + 2 * C * n_out + 24 * n_out
+    out.append({"config": f"from [T,{side * side},C] bf16: T={T} {side}x{side}x{C} -> bilinear 14x14 -> STTM(0.85,0.55), pool fused into the leaf load",
+                "videos_per_s_per_gpu": round(vps_f, 1), "us_per_video": round(1e6 / vps_f, 1),
+                "two_step_us_per_video": round(1e6 / vps_2, 1), "keep_ratio": round(n_out / (T * 196), 4),
+                "algorithmic_MB": round(B / 1e6, 2), "pool_videos": npool, "pool_MB": round(npool * 2 * C * T * side * side / 1e6, 1),
+                "achieved_GBs": round(B * vps_f / 1e9, 1), "frac": round(B * vps_f / 1e9 / HBM_PEAK_GBS, 4),
+                "frac_of_copy_rate": round(B * vps_f / 1e9 / HBM_COPY_GBS, 4)})
+    log(f"config from [T,729,C] bf16: fused {1e6 / vps_f:.1f} us, two-step {1e6 / vps_2:.1f} us per video, frac {out[-1]['frac']}")
+    del src
     # config 5's ToMe half: T = 180, ratio 0.5 (run_vidqa.sh:44), fp32 and the bf16 hidden states of production
     T, C, H, W = 180, 1024, 14, 14
     n_tok = T * H * W

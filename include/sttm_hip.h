@@ -237,7 +237,7 @@ int sttm_quadtree_merge_batch(int n_videos, const void* const* x, int64_t stride
  *   "no_fuse"     1: stand-alone label stage as two launches (no in-kernel grid barrier)
  *   "force_gmem_labels"  1: label stage on global scratch instead of LDS (the path of columns too large for LDS)
  *   "batch_streams" / "batch_sub"   sttm_quadtree_merge_batch: internal streams (default 3; <= 1 = lockstep form) and videos per launch
- *                 set on a stream (default 1, at most STTM_BATCH_MAX)
+ *                 set on a stream (default 8, at most STTM_BATCH_MAX)
  *   "tome_split"  ToMe match kernel for float32 inputs.  1 (default): unit rows as two fp16 planes (h + l of 4096 v, residual
  *                 <= 2^-23), scores from the products l.l + l.h + h.l + h.h on the fp16 matrix pipe with fp32 accumulation
  *                 (each product exact; error bound 2.4e-7 + the fp32 accumulation, measured <= 9.2e-7 against float64 where
@@ -306,6 +306,24 @@ int sttm_tome_step(const void* x, const float* size, const int64_t* idx, int n, 
 #define STTM_POOL_NEAREST 3   /* only through sttm_resize_nearest */
 int sttm_pool2d_out_side(int side, int stride, int mode);
 int sttm_pool2d(const void* x, int T, int H, int W, int C, int dtype, int mode, int stride, void* out, void* stream);
+
+/*
+ * The merge reading the UNPOOLED token map: get_2dPool (llava/model/llava_arch.py:173-198) fused into the leaf
+ * load of the spatial kernel -- every leaf of the H x W quadtree grid is built from its four source tokens on the fly, so the pooled
+ * map is neither written nor re-read.  Same results as  sttm_pool2d(x_tokens -> pooled)  followed by  sttm_quadtree_merge(pooled).
+ *   x_tokens   [T, src_h * src_w, C] row-major (e.g. 27 x 27 = 729 projected SigLIP tokens per frame, video_feat_llavavideo.py:89-95)
+ *   pool_mode / pool_stride   as sttm_pool2d: STTM_POOL_BILINEAR with any stride >= 2, STTM_POOL_AVERAGE / STTM_POOL_MAX with stride 2
+ *   H = W = sttm_pool2d_out_side(src, pool_stride, pool_mode) is the quadtree's grid: workspace >= sttm_quadtree_workspace_bytes(T, H, W, C,
+ *   dtype, root_level), outputs [T*H*W, ...] worst case as in sttm_quadtree_merge; counts_host / seq as in sttm_quadtree_merge_async.
+ * STTM_ERR_UNSUPPORTED (pool with sttm_pool2d, then call sttm_quadtree_merge): trees that are not 3 levels deep for this grid / root_level
+ * (every run_vidqa.sh preset is: 27 -> 14 x 14, root_level 1), rows that are not 16-byte aligned multiples of 16 bytes, other strides of
+ * the average / max pool.  Whole-vector cosine only (the LLaVA-Video hook that follows get_2dPool passes head_dim only with sim_per_head).
+ */
+int sttm_quadtree_merge_pooled(const void* x_tokens, int T, int src_h, int src_w, int C, int dtype, int pool_mode, int pool_stride,
+                               float threshold, float temporal_thresh, int root_level, int weighted_avg, int slow_ver,
+                               void* workspace, size_t workspace_bytes,
+                               void* feat_out, int32_t* npatch_out, int32_t* tlbr_out, int32_t* counts,
+                               int32_t* counts_host, int seq, void* stream);
 
 /*
  * Nearest-neighbour resize of every frame to OH x OW: the "pyrd" baseline's F.interpolate(video, size=(s, s))

@@ -52,7 +52,7 @@ Config& config() {
         d.tome_flat = env_int("STTM_TOME_FLAT", 1);
         d.tome_rank = env_int("STTM_TOME_RANK", 0);
         d.batch_streams = env_int("STTM_BATCH_STREAMS", 3);
-        d.batch_sub = env_int("STTM_BATCH_SUB", 1);
+        d.batch_sub = env_int("STTM_BATCH_SUB", 8);
         return d;
     }();
     return c;
@@ -323,6 +323,8 @@ void mark(void* const* events, int i, hipStream_t s) {
 
 // a caller's node list for the stand-alone temporal stage (sttm_temporal_merge)
 struct NodeList { const void* feat; const int32_t* tlbr; int n; };
+// the unpooled token map of sttm_quadtree_merge_pooled: x is [T, src_h * src_w, C]; H x W of the call is the pooled grid
+struct PoolSrc { int src_h, src_w, mode, stride; };
 
 // The merge of up to kBatchMax same-shaped videos in one set of launches.
 int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c, int64_t stride_h, int64_t stride_w,
@@ -332,7 +334,7 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
                 void* const* feat_out, int32_t* const* npatch_out, int32_t* const* tlbr_out, int32_t* counts,
                 int32_t* counts_host, int seq, void* const* events, hipStream_t stream,
                 uint64_t* early_host = nullptr, int* n_early = nullptr, int flags = 0, int32_t* idx_out = nullptr,
-                const NodeList* nodes = nullptr) {
+                const NodeList* nodes = nullptr, const PoolSrc* pool = nullptr) {
     if (n_early) *n_early = 0;
     if (!x || !workspace || !feat_out || !npatch_out || !tlbr_out || !counts) return fail(STTM_ERR_ARG, "null pointer argument");
     if (nodes && nv != 1) return fail(STTM_ERR_UNSUPPORTED, "the stand-alone temporal stage takes one video");
@@ -369,8 +371,14 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
     }
     const void* x_align = reinterpret_cast<const void*>(all_bits);      // the least aligned of the inputs decides the pack width
     int nt = 0;
-    if (int rc = check_frame_addressing(H, W, C, (int)elem_bytes(dtype), stride_h, stride_w, stride_t)) return rc;
-    const int vec = pick_vec(C, dtype, x_align, stride_t, stride_h, stride_w, &nt, head_dim == 0);
+    if (int rc = check_frame_addressing(pool ? pool->src_h : H, pool ? pool->src_w : W, C, (int)elem_bytes(dtype), stride_h, stride_w, stride_t)) return rc;
+    const int vec = pick_vec(C, dtype, x_align, stride_t, stride_h, stride_w, &nt, head_dim == 0 && !pool);
+    if (pool) {
+        // the fused pooled-leaf load exists for the shape the production presets use: 3-level trees, 16-byte packs, whole-vector cosine
+        if (p.dims.n_level != 3 || head_dim != 0 || vec * (int)elem_bytes(dtype) != 16)
+            return fail(STTM_ERR_UNSUPPORTED, "pooled input: the fused form needs a 3-level tree (got %d levels), the whole-vector cosine and 16-byte "
+                        "aligned rows with C %% %d == 0; pool with sttm_pool2d and call sttm_quadtree_merge instead", p.dims.n_level, 16 / (int)elem_bytes(dtype));
+    }
     if (!vec) return fail(STTM_ERR_UNSUPPORTED, "C=%d with this alignment does not fit one workgroup (need C/vec <= 1024 lanes)", C);
     int n_head = 0, head_lanes = 0;
     if (head_dim > 0) {
@@ -394,7 +402,11 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
     sa.sum_mode = weighted_avg ? 1 : 0;
     sa.n_head = n_head; sa.head_lanes = head_lanes;
     // dense [T*H*W, C] input: the rows of 1x1 nodes are read from x by the later kernels instead of being copied to S
-    const bool dense = !nodes && stride_w == C && stride_h == (int64_t)W * C && stride_t == (int64_t)H * W * C;
+    const bool dense = !nodes && !pool && stride_w == C && stride_h == (int64_t)W * C && stride_t == (int64_t)H * W * C;
+    if (pool) {
+        sa.src_h = pool->src_h; sa.src_w = pool->src_w; sa.pool_mode = pool->mode;
+        sa.pool_sh = (float)pool->src_h / (float)H; sa.pool_sw = (float)pool->src_w / (float)W;
+    }
     sa.leaves_in_x = dense ? 1 : 0;
     sa.k1_var = cfg.k1_var;
     sa.S = b.S; sa.meta = b.meta; sa.inrm = b.inrm; sa.rc_list = b.rc_list;
@@ -465,6 +477,9 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
     if (nodes) {
         if ((e = sttm::launch_ingest_nodes(ta, nodes->feat, nodes->tlbr, nodes->n, b.S, b.meta, b.inrm, b.rc_list, b.cgeo, stream)) != hipSuccess)
             return fail(STTM_ERR_LAUNCH, "node ingest: %s", hipGetErrorString(e));
+    } else if (pool) {
+        if ((e = sttm::launch_spatial_pooled(sa, bp, nv, dtype, nt, stream)) != hipSuccess)
+            return fail(STTM_ERR_LAUNCH, "spatial kernel (pooled input): %s", hipGetErrorString(e));
     } else if ((e = sttm::launch_spatial(sa, bp, nv, dtype, vec, nt, stream, tops)) != hipSuccess)
         return fail(STTM_ERR_LAUNCH, "spatial kernel: %s", hipGetErrorString(e));
     mark(events, 1, stream);
@@ -622,6 +637,24 @@ int sttm_quadtree_merge_packed(sttm_merge_args* g) {
                                g->early_host, &n_early, g->flags, g->idx_out);
     g->n_early = n_early;
     return rc;
+}
+
+int sttm_quadtree_merge_pooled(const void* x_tokens, int T, int src_h, int src_w, int C, int dtype, int pool_mode, int pool_stride,
+                               float threshold, float temporal_thresh, int root_level, int weighted_avg, int slow_ver,
+                               void* workspace, size_t workspace_bytes,
+                               void* feat_out, int32_t* npatch_out, int32_t* tlbr_out, int32_t* counts,
+                               int32_t* counts_host, int seq, void* stream_) {
+    if (src_h < 1 || src_w < 1 || pool_stride < 1) return fail(STTM_ERR_ARG, "bad source grid / stride");
+    if (pool_mode < STTM_POOL_AVERAGE || pool_mode > STTM_POOL_BILINEAR) return fail(STTM_ERR_ARG, "Unexpected mm_spatial_pool_mode: %d", pool_mode);
+    if (pool_stride == 1) return fail(STTM_ERR_ARG, "stride 1 is the identity (get_2dPool returns its input): call sttm_quadtree_merge");
+    if (pool_mode != STTM_POOL_BILINEAR && pool_stride != 2)
+        return fail(STTM_ERR_UNSUPPORTED, "the fused form of the average / max pool is the 2 x 2 window (stride 2); pool with sttm_pool2d instead");
+    const int H = sttm_pool2d_out_side(src_h, pool_stride, pool_mode), W = sttm_pool2d_out_side(src_w, pool_stride, pool_mode);
+    if (H < 1 || W < 1) return fail(STTM_ERR_ARG, "pooling window larger than the grid");
+    const PoolSrc pool{src_h, src_w, pool_mode, pool_stride};
+    return merge_group(1, &x_tokens, (int64_t)src_h * src_w * C, 1, (int64_t)src_w * C, C, T, C, H, W, dtype, threshold, temporal_thresh,
+                       root_level, weighted_avg, 0, slow_ver, workspace, workspace_bytes, &feat_out, &npatch_out, &tlbr_out, counts,
+                       counts_host, seq, nullptr, reinterpret_cast<hipStream_t>(stream_), nullptr, nullptr, 0, nullptr, nullptr, &pool);
 }
 
 int sttm_quadtree_merge_batch(int n_videos, const void* const* x, int64_t stride_t, int64_t stride_c, int64_t stride_h, int64_t stride_w,

@@ -22,15 +22,6 @@ struct PoolArgs {
     float sh, sw;
 };
 
-__device__ __forceinline__ void bilinear_tap(float scale, int o, int n_in, int& i0, int& i1, float& l0, float& l1) {
-    float src = __builtin_fmaf(scale, (float)o + 0.5f, -0.5f);
-    src = src < 0.f ? 0.f : src;
-    i0 = (int)src;
-    i1 = i0 + 1 < n_in ? i0 + 1 : n_in - 1;
-    l1 = src - (float)i0;
-    l0 = 1.f - l1;
-}
-
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256) k_pool2d(PoolArgs a) {
     const int P = a.C / VEC;

@@ -292,4 +292,17 @@ __device__ __forceinline__ int wave_reduce_slot(int lane, bool& valid) {
     return idx;
 }
 
+// Source taps of one output coordinate of F.interpolate(mode="bilinear", align_corners=False) (ATen's area_pixel_compute_source_index +
+// guard): shared by the stand-alone pooling kernel (pool2d.hip) and the spatial kernel's fused pooled-leaf load.  One rounding per
+// operation, the source index through ONE fused multiply-add like the ATen builds (oracle/pool_oracle.py's note on index 8 of 27 -> 14).
+__device__ __forceinline__ void bilinear_tap(float scale, int o, int n_in, int& i0, int& i1, float& l0, float& l1) {
+#pragma clang fp contract(off)
+    float src = __builtin_fmaf(scale, (float)o + 0.5f, -0.5f);
+    src = src < 0.f ? 0.f : src;
+    i0 = (int)src;
+    i1 = i0 + 1 < n_in ? i0 + 1 : n_in - 1;
+    l1 = src - (float)i0;
+    l0 = 1.f - l1;
+}
+
 }  // namespace sttm

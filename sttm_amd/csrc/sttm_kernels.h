@@ -50,6 +50,10 @@ struct SpatialArgs {
     int head_lanes;           // head_dim / vec: adjacent lanes that own one head (power of two <= 64)
     int leaves_in_x;          // x is a dense [T*H*W, C] matrix: 1x1 nodes are NOT copied to S (consumers read x)
     int k1_var;               // option (A/B, tests): 1 = interior root cells also run the general body
+    // upstream pooling fused into the leaf load (k_spatial_pooled): x is the UNPOOLED [T, src_h * src_w, C] token map (sT / sH / sW
+    // are ITS strides), H x W the pooled grid; pool_mode = STTM_POOL_*, pool_sh / pool_sw = src / out (bilinear source scale)
+    int src_h, src_w, pool_mode;
+    float pool_sh, pool_sw;
     // outputs
     void* S;                  // [T*H*W, C] node features at their origin rows (input dtype)
     uint32_t* meta;           // [T*H*W] 0 = no node starts here, else (y2 << 16) | x2
@@ -91,6 +95,8 @@ inline size_t split_ufeat_bytes(int T, const LevelDims& d, int C, int elem_bytes
 // whole-vector cosine only); tops = [T][h_block_level][w_block_level][C] elements of the input dtype per video, inside the workspace
 hipError_t launch_spatial(const SpatialArgs& a, const BatchPtrs& bp, int n_videos, int dtype, int vec, int nt, hipStream_t stream, void* tops = nullptr);
 hipError_t launch_node_apply(const SpatialArgs& a, int dtype, int vec, int nt, hipStream_t stream);
+// 3-level trees, 16-byte packs, whole-vector cosine: the spatial stage reading the unpooled token map (a.src_h x a.src_w, a.pool_mode)
+hipError_t launch_spatial_pooled(const SpatialArgs& a, const BatchPtrs& bp, int n_videos, int dtype, int nt, hipStream_t stream);
 
 struct TemporalArgs {
     int T, H, W, C, R;        // R = root cells per frame

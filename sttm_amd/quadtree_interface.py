@@ -555,6 +555,86 @@ def get_quadtree_features_into(dest, _video_feature, threshold, temporal_thresh=
 get_quadtree_features_into.returns_idx = True        # patch_hooks._merge_concat asks for merged_token_1d_idx along with the merge
 
 
+_POOL_MODES = {"average": 0, "max": 1, "bilinear": 2}
+
+
+def get_quadtree_features_from_pooled_input(image_feature, threshold, temporal_thresh=-1.0, root_level=0, weighted_avg=False,
+                                            slow_ver=False, head_dim=None, *, stride=2, mode="bilinear", width=-1,
+                                            num_patches_per_side=None):
+    """get_quadtree_features on the tokens BEFORE `get_2dPool`: `image_feature` is the projected vision-token map
+    [T, side*side, C] (LLaVA-Video: 27 x 27 = 729 tokens per frame, llava/eval/video_feat_llavavideo.py:89-95 after the projector) and
+    the call returns what the reference computes in two steps,
+
+        pooled = get_2dPool(image_feature, stride)                         # llava/model/llava_arch.py:173-198 (mode = mm_spatial_pool_mode)
+        get_quadtree_features(rearrange(pooled, "t (h w) c -> t c h w"), threshold, temporal_thresh, root_level, ...)
+
+    with the pooling FUSED into the spatial kernel's leaf load (`sttm_quadtree_merge_pooled`): the 4 source tokens of every leaf are read
+    once, the pooled map is never written or re-read.  Shapes the fused kernel does not cover (trees that are not 3 levels deep, per-head
+    cosine, odd channel counts, strides other than 2 for average / max) run the same two steps on the device: `sttm_pool2d`, then the merge.
+    Returns (features [N', C], num_patches [N'], tlbr [N', 5]) over the pooled grid."""
+    import math
+    x = image_feature
+    if stride == 1:                                                         # get_2dPool's identity case (:174-175)
+        T, n_tok, C = x.shape
+        side = num_patches_per_side if (width == -1 and num_patches_per_side is not None) else (int(round(math.sqrt(n_tok))) if width == -1 else width)
+        return get_quadtree_features(x.reshape(T, side, n_tok // side, C).permute(0, 3, 1, 2), threshold, temporal_thresh, root_level,
+                                     weighted_avg, False, slow_ver, head_dim)
+    if mode not in _POOL_MODES:
+        raise ValueError(f"Unexpected mm_spatial_pool_mode: {mode}")        # :194-195
+    if not x.is_cuda:
+        raise RuntimeError("sttm_amd runs on the GPU only: the input must be a CUDA (ROCm) tensor; there is no CPU fallback")
+    if x.dim() != 3:
+        raise ValueError("expected a [num_frames, num_tokens, C] tensor")
+    dtype = _DTYPE_CODE.get(x.dtype)
+    if dtype is None:
+        raise NotImplementedError(f"dtype {x.dtype} is not supported (float32, bfloat16, float16)")
+    T, n_tok, C = x.shape
+    if width == -1:
+        side_h = side_w = num_patches_per_side if num_patches_per_side is not None else int(round(math.sqrt(n_tok)))
+    else:
+        side_h = side_w = width
+    if side_h * side_w != n_tok:                                            # the reference's .view() fails the same way (:181)
+        raise RuntimeError("shape '[%d, %d, %d, -1]' is invalid for input of size %d" % (T, side_h, side_w, x.numel()))
+    lib = _lib.load()
+    m = _POOL_MODES[mode]
+    H, W = lib.sttm_pool2d_out_side(side_h, int(stride), m), lib.sttm_pool2d_out_side(side_w, int(stride), m)
+    if H < 1 or W < 1:
+        _lib.raise_for(_lib.ERR_ARG)
+    x = x.contiguous()
+    eb = x.element_size()
+    fused = (head_dim is None and (mode == "bilinear" or int(stride) == 2) and (C * eb) % 16 == 0 and x.data_ptr() % 16 == 0
+             and lib.sttm_quadtree_num_levels(H, W, int(root_level)) == 3)
+    if not fused:
+        from .upstream import get_2dPool
+        pooled = get_2dPool(x, stride=stride, width=side_w, mode=mode)
+        return get_quadtree_features(pooled.reshape(T, H, W, C).permute(0, 3, 1, 2), threshold, temporal_thresh, root_level,
+                                     weighted_avg, False, slow_ver, head_dim)
+    dev = x.device
+    N = T * H * W
+    with torch.cuda.device(dev):
+        st = _acquire_state(dev)
+        try:
+            nbytes = _workspace_bytes(lib, T, H, W, C, dtype, root_level)
+            st.reserve(dev, nbytes, 16)
+            st.key = None                                                   # (the argument block of the plain merge is not what ran last)
+            feat = torch.empty((N, C), dtype=x.dtype, device=dev)
+            npatch = torch.empty(N, dtype=torch.int32, device=dev)
+            tlbr = torch.empty((N, 5), dtype=torch.int32, device=dev)
+            seq = _next_seq()
+            rc = lib.sttm_quadtree_merge_pooled(x.data_ptr(), T, side_h, side_w, C, dtype, m, int(stride), float(threshold), float(temporal_thresh),
+                                                int(root_level), int(bool(weighted_avg)), int(bool(slow_ver)), st.ws.data_ptr(), st.ws.numel(),
+                                                feat.data_ptr(), npatch.data_ptr(), tlbr.data_ptr(), st.counts.data_ptr(), st.host_ptr, seq, st.handle)
+            _lib.raise_for(rc)
+            if lib.sttm_wait_counts(st.host_ptr, seq, _WAIT_TIMEOUT_US) != 0:
+                st.host_view.copy_(st.counts[0], non_blocking=True)        # fallback: classic D2H + stream sync
+                torch.cuda.current_stream(dev).synchronize()
+            cnt = st.host_view.tolist()
+        finally:
+            st.lock.release()
+    _check_overflow(cnt[_lib.CNT_OVERFLOW], cnt)
+    return _sized(feat, npatch, tlbr, cnt[_lib.CNT_OUT])
+
+
 def temporal_merge_nodes(node_features, node_tlbr, temporal_thresh, weighted_avg=False, head_dim=None, *, grid, root_level, slow_ver=False):
     """Extension: the temporal stage alone on a node list in ANY order (C ABI: `sttm_temporal_merge`).
 

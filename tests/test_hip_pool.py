@@ -151,3 +151,104 @@ def test_feature_files_of_the_reference_feed_the_merge_path(tmp_path):
     assert torch.equal(out[2].cpu(), exp[2])
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         load_qwen2vl_features(str(path2), "cpu")
+
+
+# ---- get_2dPool fused into the spatial kernel's leaf load (sttm_quadtree_merge_pooled) -------------------------------
+
+FUSED_POOL_CASES = [
+    # (T, side, C, stride, mode, dtype, spatial thr, temporal thr, root_level, weighted, slow)
+    (8, 27, 1024, 2, "bilinear", torch.float32, 0.85, 0.55, 1, False, False),     # 27 x 27 -> 14 x 14, the LLaVA-Video layout
+    (6, 27, 3584, 2, "bilinear", torch.bfloat16, 0.85, 0.55, 1, False, False),    # production width (7B), bf16 hidden states
+    (5, 27, 512, 2, "bilinear", torch.float16, 0.80, 0.50, 1, False, False),
+    (6, 27, 256, 2, "bilinear", torch.float32, 0.85, -1.0, 1, False, False),      # spatial stage only
+    (6, 27, 256, 2, "bilinear", torch.float32, 0.80, 0.50, 1, True, False),       # weighted_avg (sum-pool pyramid over pooled leaves)
+    (6, 27, 256, 2, "bilinear", torch.float32, 0.85, 0.55, 1, False, True),       # slow_ver
+    (5, 28, 256, 2, "average", torch.float32, 0.85, 0.55, 1, False, False),       # 2 x 2 average window
+    (5, 28, 512, 2, "max", torch.bfloat16, 0.85, 0.55, 1, False, False),          # 2 x 2 max window
+    (4, 40, 256, 3, "bilinear", torch.float32, 0.85, 0.55, 1, False, False),      # stride 3: 40 -> 14
+    (4, 25, 128, 2, "bilinear", torch.bfloat16, 0.85, 0.60, 1, False, False),     # 25 -> 13 x 13 (odd pooled grid)
+]
+
+
+def _smooth_tokens(T, side, C, seed, dtype):
+    """projector-like tokens with spatial and temporal redundancy (so that nodes of every size and cross-frame merges occur)"""
+    g = torch.Generator().manual_seed(seed)
+    base = torch.randn(1, 1, 1, C, generator=g)
+    coarse = torch.randn(T, (side + 7) // 8, (side + 7) // 8, C, generator=g) * 0.6
+    coarse = coarse.repeat_interleave(8, 1).repeat_interleave(8, 2)[:, :side, :side]
+    drift = torch.randn(T, 1, 1, C, generator=g).cumsum(0) * 0.05
+    x = base + coarse + drift + 0.25 * torch.randn(T, side, side, C, generator=g)
+    return x.reshape(T, side * side, C).to(dtype)
+
+
+@pytest.mark.parametrize("case", FUSED_POOL_CASES, ids=lambda c: "T%d_s%d_C%d_st%d_%s" % c[:5])
+def test_fused_pooled_input_equals_pool_then_merge(case):
+    """`get_quadtree_features_from_pooled_input` (the pool fused into K1's leaf load) against (a) pool_oracle o sttm_oracle on the CPU and
+    (b) the device's own two-step form: identical indices, features bit-identical to the two-step form."""
+    from oracle import pool_oracle as P
+    from oracle import sttm_oracle as O
+    from sttm_amd import get_quadtree_features, get_quadtree_features_from_pooled_input
+    from sttm_amd.upstream import get_2dPool
+    T, side, C, stride, mode, dtype, thr, tthr, root, weighted, slow = case
+    x = _smooth_tokens(T, side, C, 300 + T + C, dtype)
+    pooled = P.get_2dpool(x, stride, side, side, mode)
+    hw = int(round(pooled.shape[1] ** 0.5))
+    ef, en, et = O.get_quadtree_features(pooled.reshape(T, hw, hw, C).permute(0, 3, 1, 2), thr, tthr, root, weighted, slow_ver=slow)
+    f, n, t = get_quadtree_features_from_pooled_input(x.to(DEV), thr, tthr, root, weighted, slow, stride=stride, mode=mode, width=side)
+    assert torch.equal(t.cpu(), et) and torch.equal(n.cpu(), en)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert float((f.float().cpu() - ef.float()).abs().max()) <= tol
+    dp = get_2dPool(x.to(DEV), stride=stride, width=side, mode=mode)
+    f2, n2, t2 = get_quadtree_features(dp.reshape(T, hw, hw, C).permute(0, 3, 1, 2), thr, tthr, root, weighted, slow_ver=slow)
+    assert torch.equal(t, t2) and torch.equal(n, n2) and torch.equal(f, f2)
+    assert 0 < f.shape[0] < T * hw * hw                       # the case really merges something
+
+
+@pytest.mark.parametrize("path", [p for p in GOLDEN if "bilinear_27_s2" in os.path.basename(p)], ids=os.path.basename)
+def test_fused_pooled_input_on_the_reference_generated_pool_vectors(path):
+    """The `pool_bilinear_27_s2*` vectors (inputs + what the REFERENCE's get_2dPool returned): the fused call on the input equals the
+    merge of the reference's pooled output."""
+    from oracle import sttm_oracle as O
+    from sttm_amd import get_quadtree_features_from_pooled_input
+    meta, x, y = load_pool_case(path)
+    T, _, C = x.shape
+    hw = int(round(y.shape[1] ** 0.5))
+    for thr, tthr in ((0.85, 0.55), (0.6, 0.4)):
+        ef, en, et = O.get_quadtree_features(y.reshape(T, hw, hw, C).permute(0, 3, 1, 2), thr, tthr, 1)
+        f, n, t = get_quadtree_features_from_pooled_input(x.to(DEV), thr, tthr, 1, stride=meta["stride"], mode=meta["mode"],
+                                                          num_patches_per_side=meta["side"])
+        if (C * x.element_size()) % 16 == 0:                 # (narrow vectors take the two-step form: same check)
+            pass
+        assert torch.equal(t.cpu(), et) and torch.equal(n.cpu(), en)
+        assert float((f.float().cpu() - ef.float()).abs().max()) <= (1e-5 if x.dtype == torch.float32 else 2e-2)
+
+
+def test_fused_pooled_input_falls_back_and_rejects_like_get_2dpool():
+    from oracle import pool_oracle as P
+    from oracle import sttm_oracle as O
+    from sttm_amd import _lib, get_quadtree_features_from_pooled_input
+    x = _smooth_tokens(4, 27, 96, 9, torch.float32)
+    # root_level 0 on 14 x 14 is a 4-level tree, head_dim is the per-head cosine: both take pool2d + merge on the device
+    for kw in (dict(root_level=0), dict(root_level=1, head_dim=32)):
+        pooled = P.get_2dpool(x, 2, 27, 27, "bilinear").reshape(4, 14, 14, 96).permute(0, 3, 1, 2)
+        ef, en, et = O.get_quadtree_features(pooled, 0.85, 0.55, kw["root_level"], head_dim=kw.get("head_dim"))
+        f, n, t = get_quadtree_features_from_pooled_input(x.to(DEV), 0.85, 0.55, kw["root_level"], head_dim=kw.get("head_dim"))
+        assert torch.equal(t.cpu(), et) and torch.equal(n.cpu(), en)
+    with pytest.raises(ValueError, match="Unexpected mm_spatial_pool_mode"):
+        get_quadtree_features_from_pooled_input(x.to(DEV), 0.85, mode="nearest")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        get_quadtree_features_from_pooled_input(x, 0.85)
+    # the C ABI says UNSUPPORTED for what the fused kernel does not cover (and nothing is launched)
+    lib = _lib.load()
+    d = x.to(DEV)
+    ws = torch.empty(lib.sttm_quadtree_workspace_bytes(4, 14, 14, 96, 0, 0), dtype=torch.uint8, device=DEV)
+    out = torch.empty(4 * 196, 96, device=DEV); npc = torch.empty(4 * 196, dtype=torch.int32, device=DEV)
+    tl = torch.empty(4 * 196, 5, dtype=torch.int32, device=DEV); cnt = torch.zeros(8, dtype=torch.int32, device=DEV)
+    args = lambda root, mode, stride: (d.data_ptr(), 4, 27, 27, 96, 0, mode, stride, 0.85, 0.55, root, 0, 0, ws.data_ptr(), ws.numel(),   # noqa: E731
+                                       out.data_ptr(), npc.data_ptr(), tl.data_ptr(), cnt.data_ptr(), None, 0, torch.cuda.current_stream().cuda_stream)
+    assert lib.sttm_quadtree_merge_pooled(*args(0, 2, 2)) == _lib.ERR_UNSUPPORTED          # 4-level tree
+    assert lib.sttm_quadtree_merge_pooled(*args(1, 0, 3)) == _lib.ERR_UNSUPPORTED          # 3 x 3 average window
+    assert lib.sttm_quadtree_merge_pooled(*args(1, 2, 1)) == _lib.ERR_ARG                  # stride 1 = identity
+    assert lib.sttm_quadtree_merge_pooled(*args(1, 7, 2)) == _lib.ERR_ARG                  # unknown mode
+    assert lib.sttm_quadtree_merge_pooled(*args(1, 2, 2)) == 0
+    torch.cuda.synchronize()
