@@ -280,7 +280,7 @@ int sttm_merge_dst_idx(const int32_t* pairs, int L, int N, int32_t* rep_out, voi
  * dtype-representable values).
  *
  *   x          [n, C] row-major tokens          size  [n] token sizes, or NULL for all ones (first iteration)
- *   idx        [n] int64 token ids              r     tokens to remove, 1 <= r <= n / 2 (callers clamp like :26)
+ *   idx        [n] int64 token ids, or NULL for 0..n-1 (first iteration)    r     tokens to remove, 1 <= r <= n / 2 (callers clamp like :26)
  *   x_out      [n - r, C]   size_out [n - r]    idx_out [n - r]
  *              rows: the (ceil(n/2) - r) unmerged even tokens in descending best-score order, then every odd token
  *              in original order with its merged sources folded in (size-weighted average, sources added in rank order)

@@ -375,9 +375,10 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
     const int vec = pick_vec(C, dtype, x_align, stride_t, stride_h, stride_w, &nt, head_dim == 0 && !pool);
     if (pool) {
         // the fused pooled-leaf load exists for the shape the production presets use: 3-level trees, 16-byte packs, whole-vector cosine
-        if (p.dims.n_level != 3 || head_dim != 0 || vec * (int)elem_bytes(dtype) != 16)
+        if (p.dims.n_level != 3 || head_dim != 0 || vec * (int)elem_bytes(dtype) != 16 || H > sttm::kPoolMaxSide || W > sttm::kPoolMaxSide)
             return fail(STTM_ERR_UNSUPPORTED, "pooled input: the fused form needs a 3-level tree (got %d levels), the whole-vector cosine and 16-byte "
-                        "aligned rows with C %% %d == 0; pool with sttm_pool2d and call sttm_quadtree_merge instead", p.dims.n_level, 16 / (int)elem_bytes(dtype));
+                        "aligned rows with C %% %d == 0, a pooled grid of at most %d x %d; pool with sttm_pool2d and call sttm_quadtree_merge instead",
+                        p.dims.n_level, 16 / (int)elem_bytes(dtype), sttm::kPoolMaxSide, sttm::kPoolMaxSide);
     }
     if (!vec) return fail(STTM_ERR_UNSUPPORTED, "C=%d with this alignment does not fit one workgroup (need C/vec <= 1024 lanes)", C);
     int n_head = 0, head_lanes = 0;

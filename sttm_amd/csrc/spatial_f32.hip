@@ -4,5 +4,4 @@
 namespace sttm {
 template hipError_t launch_spatial_t<float, false>(const SpatialArgs&, const BatchPtrs&, int, int, int, hipStream_t, void*);
 template hipError_t launch_apply_t<float>(const SpatialArgs&, int, int, hipStream_t);
-template hipError_t launch_spatial_pooled_t<float>(const SpatialArgs&, const BatchPtrs&, int, int, hipStream_t);
 }  // namespace sttm

@@ -1,0 +1,6 @@
+// Explicit instantiation of the pooled-input spatial kernel (spatial_pooled.inc) for one dtype.
+#include "spatial_pooled.inc"
+
+namespace sttm {
+template hipError_t launch_spatial_pooled_t<f16_t>(const SpatialArgs&, const BatchPtrs&, int, int, hipStream_t);
+}  // namespace sttm

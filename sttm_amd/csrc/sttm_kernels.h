@@ -38,6 +38,12 @@ template <typename P> __device__ __forceinline__ void shift_ptr(P*& p, size_t by
     if (p) p = reinterpret_cast<P*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<P>::type*>(p)) + bytes);
 }
 
+// Source taps of the pooled-input spatial kernel, per axis (0 = rows, 1 = columns) and pooled coordinate: the two source rows / columns
+// and their bilinear weights (average / max: rows 2o and 2o + 1, weights unused).  Built on the host with the float arithmetic of
+// bilinear_tap (sttm_common.h); passed BY VALUE as a kernel argument (2 KB), so a workgroup reads its taps with scalar loads.
+constexpr int kPoolMaxSide = 64;
+struct PoolTable { int i0[2][kPoolMaxSide], i1[2][kPoolMaxSide]; float l0[2][kPoolMaxSide], l1[2][kPoolMaxSide]; };
+
 struct SpatialArgs {
     const void* x;            // [T, H, W, C] memory (channels-last view of the logical [T, C, H, W])
     int64_t sT, sH, sW;       // element strides; the channel stride is 1
@@ -96,7 +102,7 @@ inline size_t split_ufeat_bytes(int T, const LevelDims& d, int C, int elem_bytes
 hipError_t launch_spatial(const SpatialArgs& a, const BatchPtrs& bp, int n_videos, int dtype, int vec, int nt, hipStream_t stream, void* tops = nullptr);
 hipError_t launch_node_apply(const SpatialArgs& a, int dtype, int vec, int nt, hipStream_t stream);
 // 3-level trees, 16-byte packs, whole-vector cosine: the spatial stage reading the unpooled token map (a.src_h x a.src_w, a.pool_mode)
-hipError_t launch_spatial_pooled(const SpatialArgs& a, const BatchPtrs& bp, int n_videos, int dtype, int nt, hipStream_t stream);
+hipError_t launch_spatial_pooled(const SpatialArgs& a, const BatchPtrs& bp, int n_videos, int dtype, int nt, hipStream_t stream);      // (pooled grid side <= kPoolMaxSide)
 
 struct TemporalArgs {
     int T, H, W, C, R;        // R = root cells per frame

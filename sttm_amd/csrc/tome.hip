@@ -1012,7 +1012,7 @@ __global__ void __launch_bounds__(256) k_tome_merge(const void* __restrict__ x, 
                     }
                 }
             }
-            if (lane == 0) { size_out[row] = s; idx_out[row] = idx[tok]; }
+            if (lane == 0) { size_out[row] = s; idx_out[row] = idx ? idx[tok] : (int64_t)tok; }
             continue;
         }
         const int j = row - (na - r);
@@ -1119,7 +1119,7 @@ __global__ void __launch_bounds__(256) k_tome_merge(const void* __restrict__ x, 
                 tome_st_vec<T, VEC>(x_out, (int64_t)row * C + c, acc);
             }
         }
-        if (lane == 0) { size_out[row] = stot; idx_out[row] = idx[tok]; }
+        if (lane == 0) { size_out[row] = stot; idx_out[row] = idx ? idx[tok] : (int64_t)tok; }
     }
 }
 
@@ -1189,7 +1189,7 @@ int sttm_tome_step(const void* x_, const float* size, const int64_t* idx, int n,
     using namespace sttm;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     if (dtype < 0 || dtype > 2) return STTM_ERR_ARG;
-    if (!x_ || !idx || !workspace || !x_out_ || !size_out || !idx_out) return STTM_ERR_ARG;
+    if (!x_ || !workspace || !x_out_ || !size_out || !idx_out) return STTM_ERR_ARG;       // (idx == NULL: the identity, first iteration)
     TomePlan p;
     if (tome_plan(n, C, n_head, &p) != 0) return STTM_ERR_ARG;
     if (workspace_bytes < p.total) return STTM_ERR_ARG;

@@ -560,7 +560,7 @@ _POOL_MODES = {"average": 0, "max": 1, "bilinear": 2}
 
 def get_quadtree_features_from_pooled_input(image_feature, threshold, temporal_thresh=-1.0, root_level=0, weighted_avg=False,
                                             slow_ver=False, head_dim=None, *, stride=2, mode="bilinear", width=-1,
-                                            num_patches_per_side=None):
+                                            num_patches_per_side=None, force_fused=False):
     """get_quadtree_features on the tokens BEFORE `get_2dPool`: `image_feature` is the projected vision-token map
     [T, side*side, C] (LLaVA-Video: 27 x 27 = 729 tokens per frame, llava/eval/video_feat_llavavideo.py:89-95 after the projector) and
     the call returns what the reference computes in two steps,
@@ -602,8 +602,11 @@ def get_quadtree_features_from_pooled_input(image_feature, threshold, temporal_t
         _lib.raise_for(_lib.ERR_ARG)
     x = x.contiguous()
     eb = x.element_size()
+    # rows below 4 KB (two waves per root cell) do not keep enough source rows in flight: measured bf16 C = 1024 112 us fused against
+    # 105 us in two steps, C = 2048 158 / 161, fp32 C = 1024 134 / 157, bf16 C = 3584 253 / 263 (tools/bench_pool_fused.py); force=True
+    # in the tests runs the fused kernel on every shape it supports
     fused = (head_dim is None and (mode == "bilinear" or int(stride) == 2) and (C * eb) % 16 == 0 and x.data_ptr() % 16 == 0
-             and lib.sttm_quadtree_num_levels(H, W, int(root_level)) == 3)
+             and max(H, W) <= 64 and lib.sttm_quadtree_num_levels(H, W, int(root_level)) == 3 and (force_fused or C * eb >= 4096))
     if not fused:
         from .upstream import get_2dPool
         pooled = get_2dPool(x, stride=stride, width=side_w, mode=mode)

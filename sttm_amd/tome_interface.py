@@ -31,7 +31,7 @@ def _tome_video(x_tchw, prune_ratio, n_head):
     dev = x.device
     n = x.shape[0]
     target = math.ceil(n * (1 - prune_ratio))
-    idx = torch.arange(n, device=dev, dtype=torch.int64)
+    idx = None                                                      # the identity: written by the first step's merge kernel
     size = None
     first = True
     stream = torch.cuda.current_stream(dev)
@@ -50,7 +50,7 @@ def _tome_video(x_tchw, prune_ratio, n_head):
             x_out = torch.empty((n - r, C), dtype=x.dtype, device=dev)
             size_out = torch.empty(n - r, dtype=torch.float32, device=dev)
             idx_out = torch.empty(n - r, dtype=torch.int64, device=dev)
-            rc = lib.sttm_tome_step(x.data_ptr(), size.data_ptr() if size is not None else None, idx.data_ptr(),
+            rc = lib.sttm_tome_step(x.data_ptr(), size.data_ptr() if size is not None else None, idx.data_ptr() if idx is not None else None,
                                     n, C, int(n_head), r, dtype, ws.data_ptr(), nbytes,
                                     x_out.data_ptr(), size_out.data_ptr(), idx_out.data_ptr(), None, None,
                                     stream.cuda_stream)

@@ -194,7 +194,7 @@ def test_fused_pooled_input_equals_pool_then_merge(case):
     pooled = P.get_2dpool(x, stride, side, side, mode)
     hw = int(round(pooled.shape[1] ** 0.5))
     ef, en, et = O.get_quadtree_features(pooled.reshape(T, hw, hw, C).permute(0, 3, 1, 2), thr, tthr, root, weighted, slow_ver=slow)
-    f, n, t = get_quadtree_features_from_pooled_input(x.to(DEV), thr, tthr, root, weighted, slow, stride=stride, mode=mode, width=side)
+    f, n, t = get_quadtree_features_from_pooled_input(x.to(DEV), thr, tthr, root, weighted, slow, stride=stride, mode=mode, width=side, force_fused=True)
     assert torch.equal(t.cpu(), et) and torch.equal(n.cpu(), en)
     tol = 1e-5 if dtype == torch.float32 else 2e-2
     assert float((f.float().cpu() - ef.float()).abs().max()) <= tol
@@ -216,7 +216,7 @@ def test_fused_pooled_input_on_the_reference_generated_pool_vectors(path):
     for thr, tthr in ((0.85, 0.55), (0.6, 0.4)):
         ef, en, et = O.get_quadtree_features(y.reshape(T, hw, hw, C).permute(0, 3, 1, 2), thr, tthr, 1)
         f, n, t = get_quadtree_features_from_pooled_input(x.to(DEV), thr, tthr, 1, stride=meta["stride"], mode=meta["mode"],
-                                                          num_patches_per_side=meta["side"])
+                                                          num_patches_per_side=meta["side"], force_fused=True)
         if (C * x.element_size()) % 16 == 0:                 # (narrow vectors take the two-step form: same check)
             pass
         assert torch.equal(t.cpu(), et) and torch.equal(n.cpu(), en)
