@@ -199,7 +199,9 @@ int sttm_wait_counts_early(const int32_t* counts_host, const uint64_t* early_hos
  *   workspace                           n_videos * workspace_stride bytes; workspace_stride >= sttm_quadtree_workspace_bytes(...)
  *                                       and a multiple of 256
  *   counts                              device int32[n_videos][STTM_CNT_SLOTS]
- *   counts_host                         NULL or pinned int32[n_videos][STTM_CNT_SLOTS]; video v publishes seq + v in its last slot
+ *   counts_host                         NULL or pinned int32[n_videos][STTM_CNT_SLOTS]; video v publishes seq + v in its last slot (written by
+ *                                       the group-mean kernel, i.e. late: with early_host the host learns N' one kernel earlier and can
+ *                                       prepare its next call while the feature gather of this one is still running)
  * Any n_videos >= 1.  Round 5 (stage-skewed form, default): the videos are dealt out to "batch_streams" internal streams (created on
  * first use, per host thread and device) in launch sets of "batch_sub" videos, forked from and joined back into `stream` with events, so
  * that consecutive videos sit in DIFFERENT stages at any moment; batch_streams <= 1 selects the lockstep form (every kernel once per
@@ -211,7 +213,10 @@ int sttm_quadtree_merge_batch(int n_videos, const void* const* x, int64_t stride
                               float threshold, float temporal_thresh, int root_level, int weighted_avg, int head_dim, int slow_ver,
                               void* workspace, size_t workspace_stride,
                               void* const* feat_out, int32_t* const* npatch_out, int32_t* const* tlbr_out, int32_t* counts,
-                              int32_t* counts_host, int seq, void* const* events, void* stream, int flags /* STTM_FLAG_* */);
+                              int32_t* counts_host, int seq, void* const* events, void* stream, int flags /* STTM_FLAG_* */,
+                              uint64_t* early_host /* NULL, or pinned uint64[n_videos][STTM_EARLY_SLOTS]: video v's label-stage columns store their
+                                                      words (seq + v) << 32 | flags | survivors there, as in sttm_quadtree_merge_packed */,
+                              int* n_early_out /* columns per video that report (0: not used); wait with sttm_wait_counts_early per video */);
 
 /*
  * Tuning and test switches (process-wide; none of them changes results, except "tome_split" within the fp32 rounding noise of

@@ -38,7 +38,7 @@ SIGNATURES = {
     "sttm_quadtree_merge_async": (_i, [_vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _f, _i, _i, _i, _i,
                                        _vp, _sz, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "sttm_quadtree_merge_batch": (_i, [_i, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _f, _i, _i, _i, _i,
-                                       _vp, _sz, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i]),
+                                       _vp, _sz, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
     "sttm_quadtree_merge_pooled": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "sttm_configure": (_i, [ctypes.c_char_p, _i]),
     "sttm_wait_counts": (_i, [_vp, _i, _i]),

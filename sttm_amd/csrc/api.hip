@@ -450,7 +450,8 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
     ta.counts = counts;
     ta.counts_host = counts_host; ta.seq = seq;
     // every column reports its survivors to the host itself (single video, a slot per column)
-    if (early_host && n_early && nv == 1 && p.R <= STTM_EARLY_SLOTS) {
+    // (a batch: video v reports into early_host[v * STTM_EARLY_SLOTS ...], sequence number seq + v)
+    if (early_host && n_early && p.R <= STTM_EARLY_SLOTS) {
         ta.early_host = reinterpret_cast<unsigned long long*>(early_host);
         *n_early = p.R;
     }
@@ -663,7 +664,9 @@ int sttm_quadtree_merge_batch(int n_videos, const void* const* x, int64_t stride
                               float threshold, float temporal_thresh, int root_level, int weighted_avg, int head_dim, int slow_ver,
                               void* workspace, size_t workspace_stride,
                               void* const* feat_out, int32_t* const* npatch_out, int32_t* const* tlbr_out, int32_t* counts,
-                              int32_t* counts_host, int seq, void* const* events, void* stream_, int flags) {
+                              int32_t* counts_host, int seq, void* const* events, void* stream_, int flags,
+                              uint64_t* early_host, int* n_early_out) {
+    if (n_early_out) *n_early_out = 0;
     if (n_videos < 1) return fail(STTM_ERR_ARG, "n_videos must be >= 1");
     if (!x || !feat_out || !npatch_out || !tlbr_out || !counts || !workspace) return fail(STTM_ERR_ARG, "null pointer argument");
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
@@ -689,7 +692,8 @@ int sttm_quadtree_merge_batch(int n_videos, const void* const* x, int64_t stride
                              reinterpret_cast<char*>(workspace) + (size_t)v0 * workspace_stride, workspace_stride,
                              feat_out + v0, npatch_out + v0, tlbr_out + v0, counts + (size_t)v0 * STTM_CNT_SLOTS,
                              counts_host ? counts_host + (size_t)v0 * STTM_CNT_SLOTS : nullptr, seq + v0,
-                             nullptr, pool->s[lane], nullptr, nullptr, flags);
+                             nullptr, pool->s[lane], early_host ? early_host + (size_t)v0 * STTM_EARLY_SLOTS : nullptr,
+                             early_host ? n_early_out : nullptr, flags);
         }
         // join even after a failed launch: whatever was enqueued on the internal streams stays ordered before the caller's next work
         for (int i = 0; i < S; ++i) {
@@ -714,7 +718,8 @@ int sttm_quadtree_merge_batch(int n_videos, const void* const* x, int64_t stride
                                    reinterpret_cast<char*>(workspace) + (size_t)v0 * workspace_stride, workspace_stride,
                                    feat_out + v0, npatch_out + v0, tlbr_out + v0, counts + (size_t)v0 * STTM_CNT_SLOTS,
                                    counts_host ? counts_host + (size_t)v0 * STTM_CNT_SLOTS : nullptr, seq + v0,
-                                   events ? ev : nullptr, stream, nullptr, nullptr, flags);
+                                   events ? ev : nullptr, stream, early_host ? early_host + (size_t)v0 * STTM_EARLY_SLOTS : nullptr,
+                                   early_host ? n_early_out : nullptr, flags);
         if (rc != STTM_OK) return rc;
     }
     return STTM_OK;

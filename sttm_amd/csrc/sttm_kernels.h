@@ -173,6 +173,7 @@ __device__ __forceinline__ void rebase(TemporalArgs& a, const BatchPtrs& bp, int
     shift_ptr(a.colscratch, off); shift_ptr(a.lab_row, off); shift_ptr(a.gcnt, off); shift_ptr(a.cgeo, off);
     a.counts += (size_t)v * STTM_CNT_SLOTS;
     if (a.counts_host) a.counts_host += (size_t)v * STTM_CNT_SLOTS;
+    if (a.early_host) a.early_host += (size_t)v * STTM_EARLY_SLOTS;
     a.seq += v;
 }
 // every launcher takes the arguments of video 0 plus the per-video buffers; n_videos <= kBatchMax

@@ -97,7 +97,7 @@ class _StreamState:
     the early per-column words; rows for the videos of a batch), scratch, and the ONE lock that serialises host threads which
     share the stream."""
     __slots__ = ("args", "args_ptr", "pinned", "host_ptr", "early_ptr", "host_view", "out2", "out2_ptr", "ws", "counts", "key", "lock",
-                 "idx", "handle", "evicted", "no_fuse_left", "batch_pinned", "retired")
+                 "idx", "handle", "evicted", "no_fuse_left", "batch_pinned", "batch_early", "retired", "n_early_out")
 
     def __init__(self, idx, handle):
         # one pinned block: int32[8] classic counts, then uint64[EARLY_SLOTS] early words (8-byte aligned at byte 32)
@@ -120,6 +120,8 @@ class _StreamState:
         self.evicted = False
         self.no_fuse_left = 0
         self.batch_pinned = None        # int32 [rows, CNT_SLOTS] pinned: classic counts of the videos of a batch call
+        self.batch_early = None         # int64 [rows, EARLY_SLOTS] pinned: the early per-column words of the videos of a batch call
+        self.n_early_out = ctypes.c_int(0)
         self.retired = []               # outgrown pinned pads: kept until this state itself is retired (the stream may still write them)
 
     def reserve(self, dev, nbytes, rows):
@@ -136,8 +138,10 @@ class _StreamState:
         if self.batch_pinned is None or self.batch_pinned.shape[0] < rows:
             if self.batch_pinned is not None:
                 self.retired.append(self.batch_pinned)
+                self.retired.append(self.batch_early)
             self.batch_pinned = torch.zeros((max(rows, 32), _lib.CNT_SLOTS), dtype=torch.int32).pin_memory()
-        return self.batch_pinned
+            self.batch_early = torch.zeros((max(rows, 32), _lib.EARLY_SLOTS), dtype=torch.int64).pin_memory()
+        return self.batch_pinned, self.batch_early
 
     def stream_idle(self):
         """True when everything queued on this state's stream has completed (its pinned pads are then no longer written)."""
@@ -447,35 +451,50 @@ def _batch_locked(st, videos, dev, threshold, temporal_thresh, root_level, weigh
         per_video = max(per_video, _workspace_bytes(lib, T, H, W, C, _DTYPE_CODE[dt], root_level))
     per_video = (per_video + 255) // 256 * 256
     st.reserve(dev, per_video * total, total)
-    host = st.batch_rows(total)
+    host, early = st.batch_rows(total)
+    host_base, early_base = host.data_ptr(), early.data_ptr()
     ws, counts = st.ws, st.counts
     for (shape, dt, strides), ids in groups.items():
         T, C, H, W = shape
         N = T * H * W
         n = len(ids)
-        feats = [torch.empty((N, C), dtype=dt, device=dev) for _ in ids]
-        npatches = [torch.empty(N, dtype=torch.int32, device=dev) for _ in ids]
-        tlbrs = [torch.empty((N, 5), dtype=torch.int32, device=dev) for _ in ids]
-        arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])      # noqa: E731
+        # the outputs of a group in THREE allocations (worst-case rows per video, returned as leading views like the one-video call):
+        # one torch.empty per tensor and video kept the host busy for ~7 us per video between two calls, with the device idle
+        feats = torch.empty((n, N, C), dtype=dt, device=dev)
+        npatches = torch.empty((n, N), dtype=torch.int32, device=dev)
+        tlbrs = torch.empty((n, N, 5), dtype=torch.int32, device=dev)
+        eb = feats.element_size()
+        f0, p0, t0 = feats.data_ptr(), npatches.data_ptr(), tlbrs.data_ptr()
+        vp = ctypes.c_void_p * n
         seq = _next_seq(n)
         rc = lib.sttm_quadtree_merge_batch(
-            n, arr([vids[j] for j in ids]), strides[0], strides[1], strides[2], strides[3], T, C, H, W, _DTYPE_CODE[dt],
+            n, vp(*[vids[j].data_ptr() for j in ids]), strides[0], strides[1], strides[2], strides[3], T, C, H, W, _DTYPE_CODE[dt],
             float(threshold), float(temporal_thresh), int(root_level), int(bool(weighted_avg)), head, int(bool(slow_ver)),
-            ws.data_ptr() + rows_used * per_video, per_video, arr(feats), arr(npatches), arr(tlbrs),
-            counts[rows_used].data_ptr(), host[rows_used].data_ptr(), seq,
-            events.pointer() if events is not None else None, st.handle, flags)
+            ws.data_ptr() + rows_used * per_video, per_video,
+            vp(*range(f0, f0 + n * N * C * eb, N * C * eb)), vp(*range(p0, p0 + n * N * 4, N * 4)), vp(*range(t0, t0 + n * N * 20, N * 20)),
+            counts[rows_used].data_ptr(), host_base + rows_used * 4 * _lib.CNT_SLOTS, seq,
+            events.pointer() if events is not None else None, st.handle, flags,
+            early_base + rows_used * 8 * _lib.EARLY_SLOTS, ctypes.byref(st.n_early_out))
         _lib.raise_for(rc)
+        n_early = st.n_early_out.value
         for k, j in enumerate(ids):
-            pend.append((j, feats[k], npatches[k], tlbrs[k], seq + k, rows_used + k))
+            pend.append((j, feats[k], npatches[k], tlbrs[k], seq + k, rows_used + k, n_early))
         rows_used += n
-    for j, feat, npatch, tlbr, seq, row in pend:
-        # N' of every video from pinned memory (published by the group-mean kernel's first workgroup), no stream synchronisation
-        if lib.sttm_wait_counts(host[row].data_ptr(), seq, _WAIT_TIMEOUT_US) != 0:
+    out2, out2_ptr = st.out2, st.out2_ptr
+    for j, feat, npatch, tlbr, seq, row, n_early in pend:
+        # N' of every video from pinned memory: the label stage's columns report it (one kernel before the feature gather ends), the
+        # group-mean kernel's first workgroup is the fallback; no stream synchronisation
+        if lib.sttm_wait_counts_early(host_base + row * 4 * _lib.CNT_SLOTS, early_base + row * 8 * _lib.EARLY_SLOTS, n_early, seq,
+                                      _WAIT_TIMEOUT_US, out2_ptr) != 0:
             host[row].copy_(counts[row], non_blocking=True)  # fallback: classic D2H + stream sync
             torch.cuda.current_stream(dev).synchronize()
-        cnt = host[row].tolist()
-        _check_overflow(cnt[_lib.CNT_OVERFLOW], cnt)
-        n_out = cnt[_lib.CNT_OUT]
+            cnt = host[row].tolist()
+            out2[0], out2[1] = cnt[_lib.CNT_OUT], cnt[_lib.CNT_OVERFLOW]
+        n_out, ovf = out2[0], out2[1]
+        if ovf:
+            cnt = [0] * _lib.CNT_SLOTS
+            cnt[_lib.CNT_OUT], cnt[_lib.CNT_OVERFLOW] = n_out, ovf
+            _check_overflow(ovf, cnt)
         out[j] = _sized(feat, npatch, tlbr, n_out)
     return out
 
