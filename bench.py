@@ -1,17 +1,19 @@
 #!/usr/bin/env python3
 """Benchmark of the STTM merge hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode batch|dropin]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 Workload (BASELINE.json metric): synth-v1 videos of 128 frames x 14x14 tokens x 1024 channels, fp32, in the
 production layout (channels-last view), full STTM = quadtree spatial merge (thr 0.85, root_level 1) +
 temporal merge (thr 0.55) -- the LLaVA-Video-7B / Video-MME "50 % budget" preset of the reference
-(scripts/eval/run_vidqa.sh:58).  A step = `--videos-per-step` videos through get_quadtree_features, one
-after the other (the reference API is batch-1), inputs resident in HBM, outputs (incl. the host-visible
-token count) produced.  Videos are independent, so N GPUs each take their own videos (weak scaling);
-the only collective is the final gather of the per-video token counts over RCCL (with --validate also the
-padded merged-token indices).
+(scripts/eval/run_vidqa.sh:58).  A step = `--videos-per-step` videos, inputs resident in HBM, every video's outputs
+(incl. its host-visible token count) produced.  `--mode batch` (default): get_quadtree_features_batch, `--batch`
+independent videos per call, which the library deals out to its internal streams (stage-skewed; identical outputs);
+`--mode dropin`: get_quadtree_features, one video per call on one stream (the definition of `value` in rounds 1-4).
+Whichever mode the timed region does not run is measured next to it.  Videos are independent, so N GPUs each take
+their own videos (weak scaling); the only collective is the final gather of the per-video token counts over RCCL
+(with --validate also the padded merged-token indices).
 
 `python bench.py --gpus N` without a torchrun environment spawns the N ranks itself.
 Prints ONE JSON line on rank 0 (see DESIGN.md section "Measurement" for every field).
@@ -55,7 +57,7 @@ def parse():
                     help="what the timed region (`value`) runs: 'batch' = get_quadtree_features_batch, --batch videos per call, dealt out to "
                          "the library's internal streams (stage-skewed; identical outputs); 'dropin' = get_quadtree_features, one video per "
                          "call on one stream (rounds 1-4's headline).  The other mode is always reported next to it.")
-    ap.add_argument("--batch", type=int, default=48, help="videos per get_quadtree_features_batch call in 'batch' mode")
+    ap.add_argument("--batch", type=int, default=96, help="videos per get_quadtree_features_batch call in 'batch' mode")
     ap.add_argument("--validate", action="store_true",
                     help="after the timed region, all-gather the padded merged-token indices of a sample of videos over the ranks "
                          "and check them against each rank's own recomputation")

@@ -144,7 +144,11 @@ class _StreamState:
         return self.batch_pinned, self.batch_early
 
     def stream_idle(self):
-        """True when everything queued on this state's stream has completed (its pinned pads are then no longer written)."""
+        """True when everything queued on this state's stream has completed (its pinned pads are then no longer written).
+        The stream is re-wrapped from its raw handle: torch's own streams come from a fixed per-device pool and are never destroyed, so
+        the handle of a torch stream stays valid for the life of the process; a foreign stream (torch.cuda.ExternalStream of another
+        runtime user) that its owner has destroyed is the owner's contract to keep alive until the states created on it are retired --
+        `sttm_amd.quadtree_interface.drop_stream_state(stream)` retires one explicitly."""
         try:
             s = torch.cuda.default_stream(self.idx) if not self.handle else torch.cuda.ExternalStream(self.handle, device=self.idx)
             return bool(s.query())
@@ -230,6 +234,18 @@ class _StateCache:
 
 
 _states = _StateCache(8)          # (device index, raw stream handle) -> _StreamState
+
+
+def drop_stream_state(stream):
+    """Retire the per-stream state of `stream` (a torch.cuda.Stream / ExternalStream) NOW: waits for the work queued on it, then frees
+    its scratch and pinned landing pads.  For owners of foreign streams, to be called before they destroy the stream."""
+    key = (stream.device.index, stream.cuda_stream)
+    with _states._mu:
+        st = _states._d.pop(key, None)
+    if st is not None:
+        with st.lock:
+            st.evicted = True
+        stream.synchronize()
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 

@@ -1095,6 +1095,43 @@ def test_tome_tile128_and_tile256_kernels_are_bit_identical(dtype):
         _lib.configure(tome_split=1)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_tome_rank_by_counting_and_radix_sort_paths_are_bit_identical(dtype):
+    """`argsort(node_max, descending)` with ties to the smaller index is computed either by counting in one kernel (`tome_rank = 0`, the
+    default up to 49 152 a-tokens) or by the radix sort path (`tome_rank = 1`, the path of longer clips): same order, hence the same bits --
+    on sizes that are not multiples of the rank kernel's 256-token blocks, on clips with massive exact ties (16-bit scores; duplicated
+    tokens), with NaN rows (a zero token has a 0/0 unit row), and on a clip ABOVE the counting kernel's limit, where both settings must
+    take the radix path."""
+    from sttm_amd import _lib, get_tome_features
+    from sttm_amd.synth import synth_video
+    dev = _dev()
+    try:
+        cases = [(1, 256, 0.5), (3, 1024, 0.7), (11, 128, 0.85), (40, 256, 0.6), (128, 64, 0.5)]
+        for T, C, ratio in cases:
+            x = synth_video(T, C, 14, 14, seed=700 + T, dtype=dtype).to(dev)
+            if T == 11:
+                flat = x.permute(0, 2, 3, 1)
+                flat[2] = flat[1]                          # a whole frame duplicated: hundreds of exactly equal best scores
+                flat[5, 3, 4] = 0                          # a zero token: NaN unit row, NaN scores
+                flat[6, 0, 0] = 0
+            outs = []
+            for rank in (0, 1):
+                _lib.configure(tome_rank=rank)
+                outs.append(get_tome_features(x, ratio, "video"))
+            (f0, i0), (f1, i1) = outs
+            assert torch.equal(i0, i1), f"{dtype} T={T} C={C} r={ratio}: kept-token ids differ between the rank paths"
+            assert torch.equal(f0.view(torch.int32 if dtype == torch.float32 else torch.int16), f1.view(torch.int32 if dtype == torch.float32 else torch.int16))
+        # above kRankMax a-tokens (T = 502 frames of 196 tokens = 49 196 a-tokens): the radix path whatever the switch says
+        x = synth_video(502, 16, 14, 14, seed=777, dtype=dtype).to(dev)
+        _lib.configure(tome_rank=0)
+        fa, ia = get_tome_features(x, 0.5, "video")
+        _lib.configure(tome_rank=1)
+        fb, ib = get_tome_features(x, 0.5, "video")
+        assert torch.equal(ia, ib) and torch.equal(fa, fb) and ia.shape[0] == 502 * 196 // 2
+    finally:
+        _lib.configure(tome_rank=0)
+
+
 @pytest.mark.parametrize("mode", [3, 4], ids=["tile128", "tile256_dma"])
 def test_tome_16bit_match_kernel_variants(mode):
     """Both 16-bit match kernels against the reference's vectors (bf16 / fp16 golden cases) and the oracle."""

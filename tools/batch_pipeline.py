@@ -60,7 +60,7 @@ for nth in (3, 4):
 
 combos = [(0, 16, 16), (0, 16, 48), (3, 1, 48), (2, 4, 48), (3, 4, 48), (4, 4, 48), (2, 8, 48), (3, 8, 48), (3, 3, 48), (3, 4, 96), (4, 4, 96), (2, 6, 96), (3, 6, 96), (2, 12, 96), (3, 16, 96)]
 if quick:
-    combos = [(0, 16, 16), (3, 1, 16), (3, 1, 48), (4, 1, 48)]
+    combos = [(0, 16, 16), (3, 1, 48), (4, 4, 48), (3, 8, 48), (4, 4, 96)]
 for streams, sub, B in combos:
     check(streams, sub)
 
