@@ -241,8 +241,8 @@ int sttm_quadtree_merge_batch(int n_videos, const void* const* x, int64_t stride
  *                 2: the round-3 form of the slot-indexed stage (three barriers per iteration; A/B)
  *   "no_fuse"     1: stand-alone label stage as two launches (no in-kernel grid barrier)
  *   "force_gmem_labels"  1: label stage on global scratch instead of LDS (the path of columns too large for LDS)
- *   "batch_streams" / "batch_sub"   sttm_quadtree_merge_batch: internal streams (default 4; <= 1 = lockstep form) and videos per launch
- *                 set on a stream (default 4, at most STTM_BATCH_MAX)
+ *   "batch_streams" / "batch_sub"   sttm_quadtree_merge_batch: internal streams (default 3; <= 1 = lockstep form) and videos per launch
+ *                 set on a stream (default 8, at most STTM_BATCH_MAX)
  *   "tome_split"  ToMe match kernel for float32 inputs.  1 (default): unit rows as two fp16 planes (h + l of 4096 v, residual
  *                 <= 2^-23), scores from the products l.l + l.h + h.l + h.h on the fp16 matrix pipe with fp32 accumulation
  *                 (each product exact; error bound 2.4e-7 + the fp32 accumulation, measured <= 9.2e-7 against float64 where

@@ -51,8 +51,8 @@ Config& config() {
         d.tome_split = env_int("STTM_TOME_SPLIT", 1);
         d.tome_flat = env_int("STTM_TOME_FLAT", 1);
         d.tome_rank = env_int("STTM_TOME_RANK", 0);
-        d.batch_streams = env_int("STTM_BATCH_STREAMS", 4);
-        d.batch_sub = env_int("STTM_BATCH_SUB", 4);
+        d.batch_streams = env_int("STTM_BATCH_STREAMS", 3);
+        d.batch_sub = env_int("STTM_BATCH_SUB", 8);
         return d;
     }();
     return c;
