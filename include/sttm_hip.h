@@ -226,8 +226,9 @@ int sttm_quadtree_merge_batch(int n_videos, const void* const* x, int64_t stride
  *   "pairs_seg"   consecutive frame pairs of one root cell per pair workgroup (0 = automatic: 1; with fold_labels about one
  *                 workgroup per CU)
  *   "pairs_nt"    pair-kernel block size (0 = automatic: 256 for one pair, 128 threads per pair of a run, up to 1024)
- *   "gm_split"    group-mean workgroups per frame (0 = automatic)
- *   "label_nt"    threads per column of the stand-alone label kernels (256 / 512 / 1024)
+ *   "gm_split"    group-mean workgroups per frame (0 = automatic: ~4096 / T for one video, ~1024 / T in launch sets of several videos)
+ *   "label_nt"    threads per column of the stand-alone label kernels (256 / 512 / 1024; 0 = automatic: 1024 for one video, 256 in launch
+ *                 sets of several videos)
  *   "vec16" / "vec32"   force the pack width of 16-bit / 32-bit inputs in the spatial kernel (0 = automatic)
  *   "fold_kb"     LDS budget (KB) per pair workgroup when the label stage runs inside the pair kernel (default 64)
  *   "fold_labels" 1: run a column's label stage inside the pair kernel, in the column's last workgroup to finish (default 0:

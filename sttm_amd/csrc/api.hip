@@ -41,7 +41,7 @@ Config& config() {
         d.k1_split = env_int("STTM_K1_SPLIT", 0);
         d.no_dense = env_int("STTM_NO_DENSE", 0);
         d.gm_split = env_int("STTM_GM_SPLIT", 0);
-        d.label_nt = env_int("STTM_LABEL_NT", 1024);
+        d.label_nt = env_int("STTM_LABEL_NT", 0);
         d.vec16 = env_int("STTM_VEC16", 0);
         d.vec32 = env_int("STTM_VEC32", 0);
         d.fold_kb = env_int("STTM_FOLD_KB", 64);
@@ -293,9 +293,12 @@ int octree_plan(int B, int side, int C, int dtype, int root_level, OctPlan* p) {
 }
 
 // Group-mean workgroups per frame: enough 4-wave workgroups (T * split) to cover the chip several times over.
-int gm_split_for(int T, int HW) {
+int gm_split_for(int T, int HW, int nv = 1) {
     const int env = config().gm_split;
-    const int want = env > 0 ? env : (4096 + T - 1) / T;
+    // launch sets of several videos (the batch entry point: other streams' kernels run beside this one): a quarter of the workgroups
+    // per frame -- sustained driver-style runs on one box, 3 streams x 8 videos: 18.2 k videos/s with 32 per frame and 1024-thread label
+    // columns, 19.6 k with 16 / 512, 20.4 k with 8 / 512, 20.5 k with 8 / 256 (profiles/r05v_batch_switches.txt)
+    const int want = env > 0 ? env : (nv > 1 ? (1024 + T - 1) / T : (4096 + T - 1) / T);
     int s = 1;
     while (s < want && s < 64) s <<= 1;          // a power of two: the kernel masks instead of dividing
     // frames of 512 and more tokens: every workgroup of a frame ranks ALL its survivors before it takes its share, so fewer, longer
@@ -425,7 +428,9 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
     ta.dtype = dtype; ta.vec = row_vec(C, dtype, vec, dense, all_bits % 32 == 0, head_dim);
     sttm::pairs_shape(T, p.R, cfg.fold_labels && !slow_ver, cfg.pairs_seg, cfg.pairs_nt, &ta.pairs_seg, &ta.pairs_nt);
     ta.pairs_var = cfg.pairs_var;
-    ta.label_nt = (cfg.label_nt == 256 || cfg.label_nt == 512) ? cfg.label_nt : 1024;
+    // threads per label column: 1024 for one video (the stage is the call's critical path), 256 in launch sets of several videos (the
+    // stage then runs beside other streams' bandwidth-bound kernels and should leave them the CUs)
+    ta.label_nt = (cfg.label_nt == 256 || cfg.label_nt == 512 || cfg.label_nt == 1024) ? cfg.label_nt : (nv > 1 ? 256 : 1024);
     ta.temporal_thresh = temporal_thresh;
     // the merge runs its temporal stage only for a positive threshold (quadtree_builder.py:217); cross_frame_node_merging_fast / _slow
     // themselves filter with whatever threshold they are given (quadtree_temporal_merger.py:70-71: sim >= thresh)
@@ -446,7 +451,7 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
     ta.ecap_magic = 0xffffffffu / (unsigned)p.ecap + 1u;
     ta.col_mask = b.col_mask; ta.col_arrive = b.col_arrive; ta.frame_cnt = b.frame_cnt; ta.bar = b.bar;
     ta.colscratch = b.colscratch;
-    ta.gm_split = gm_split_for(T, H * W); ta.lab_row = b.lab_row; ta.gcnt = b.gcnt; ta.cgeo = b.cgeo;
+    ta.gm_split = gm_split_for(T, H * W, nv); ta.lab_row = b.lab_row; ta.gcnt = b.gcnt; ta.cgeo = b.cgeo;
     ta.counts = counts;
     ta.counts_host = counts_host; ta.seq = seq;
     // every column reports its survivors to the host itself (single video, a slot per column)
