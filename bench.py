@@ -151,7 +151,7 @@ def run_configs(dev, rank, world, timed, log):
     shape holds >= 300 MB of distinct videos (> the 256 MB Infinity Cache: a video is not cache-resident from its previous use;
     round 3 used 3 videos per shape, which left C1 and C2 inside the cache).  The ToMe half of config 5 (T=180, r=0.5) rides along
     with its flop roofline."""
-    from sttm_amd.quadtree_interface import get_quadtree_features
+    from sttm_amd.quadtree_interface import get_quadtree_features, get_quadtree_features_batch
     from sttm_amd.synth import synth_video
     from sttm_amd.tome_interface import get_tome_features
     out = []
@@ -169,15 +169,26 @@ def run_configs(dev, rank, world, timed, log):
             for i in range(reps):
                 get_quadtree_features(pool[i % npool], thr, tthr, root)
         vps = timed(run, reps) / world                                                      # per GPU
+        # the same videos through the batch entry point (48 per call, cycling the pool)
+        nb = 48 if eb * C * T * H * W < 400e6 else 16
+        blist = [pool[i % npool] for i in range(nb)]
+        get_quadtree_features_batch(blist[:8], thr, tthr, root)
+        breps = max(1, reps // nb + 1)
+
+        def run_b(blist=blist, breps=breps, thr=thr, tthr=tthr, root=root):
+            for _ in range(breps):
+                get_quadtree_features_batch(blist, thr, tthr, root)
+        bvps = timed(run_b, breps * nb) / world
         n_out = sum(kept) / len(kept)
         B = eb * C * T * H * W + eb * C * n_out + 24 * n_out
         out.append({"config": name, "videos_per_s_per_gpu": round(vps, 1), "us_per_video": round(1e6 / vps, 1),
+                    "batch_videos_per_s_per_gpu": round(bvps, 1), "batch_frac": round(B * bvps / 1e9 / HBM_PEAK_GBS, 4),
                     "keep_ratio": round(n_out / (T * H * W), 4), "algorithmic_MB": round(B / 1e6, 2), "pool_videos": npool,
                     "pool_MB": round(npool * eb * C * T * H * W / 1e6, 1),
                     "achieved_GBs": round(B * vps / 1e9, 1), "frac": round(B * vps / 1e9 / HBM_PEAK_GBS, 4),
                     "frac_of_copy_rate": round(B * vps / 1e9 / HBM_COPY_GBS, 4)})
-        log(f"config {name}: {vps:.1f} videos/s, frac {out[-1]['frac']}")
-        del pool
+        log(f"config {name}: {vps:.1f} videos/s one call per video (frac {out[-1]['frac']}), {bvps:.1f} batch (frac {out[-1]['batch_frac']})")
+        del pool, blist
     # the step before the path: the merge starting from the UNPOOLED projector tokens [T, 729, C] bf16 (27 x 27 per frame,
     # llava/eval/video_feat_llavavideo.py:89-95 behind the projector): get_2dPool fused into the spatial kernel's leaf load against the
     # two-step form (sttm_pool2d writes the 14 x 14 map, the merge reads it back).  B = read every SOURCE token once + write every merged token.

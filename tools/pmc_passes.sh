@@ -11,7 +11,7 @@ for CNT in FETCH_SIZE WRITE_SIZE; do
     cd /tmp
     rm -rf /tmp/pmc_$CNT
     timeout 600 rocprofv3 --kernel-trace --pmc $CNT --kernel-include-regex sttm -d /tmp/pmc_$CNT -o x -- \
-        python "$REPO/bench.py" --steps 2 --warmup 1 --videos-per-step 64 --profile-calls 8 --no-cpu-baseline --no-extensions --no-configs > /dev/null 2> "$REPO/gpurun_out/pmc_$CNT.err"
+        python "$REPO/bench.py" --mode dropin --steps 2 --warmup 1 --videos-per-step 64 --profile-calls 8 --no-cpu-baseline --no-extensions --no-configs > /dev/null 2> "$REPO/gpurun_out/pmc_$CNT.err"
     cp "$(find /tmp/pmc_$CNT -name '*.db' | head -1)" "$REPO/gpurun_out/pmc_$CNT.db"
     cd "$REPO"
 done

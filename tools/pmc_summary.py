@@ -44,7 +44,7 @@ def main():
     rec = {"workload": "T128_14x14x1024_f32_sttm_0.85_0.55", "tag": tag, "build_tag": _lib.build_tag(),
            "hbm_bytes_per_video": round(sum(agg.values())),
            "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes, --kernel-include-regex sttm, "
-                     "bench.py --steps 2 --warmup 1 --videos-per-step 64; mean per launch; fetch = 2 * FETCH_SIZE KB (gfx950 correction), write = WRITE_SIZE KB",
+                     "bench.py --mode dropin --steps 2 --warmup 1 --videos-per-step 64 (one video per launch); mean per launch; fetch = 2 * FETCH_SIZE KB (gfx950 correction), write = WRITE_SIZE KB",
            "hbm_bytes_per_launch": {k: round(v) for k, v in agg.items()}}
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with open(os.path.join(root, "profiles", "pmc_traffic.json"), "w") as fh:
