@@ -70,3 +70,47 @@ def get_tome_features(_video_feature, prune_ratio, tome_ver, n_head=1):
     if tome_ver == "video":
         return _tome_video(_video_feature, prune_ratio, n_head)
     return None            # "snippet" is a stub upstream; unknown versions fall through the reference's if/elif
+
+
+_side_streams = {}      # device index -> [torch.cuda.Stream, ...]
+
+
+def get_tome_features_batch(videos, prune_ratio, tome_ver="video", n_head=1, streams=2):
+    """Extension (the reference's API is one video per call): ToMe on a LIST of independent videos, results identical to calling
+    get_tome_features on each.  A call is a chain of launches per merge iteration -- normalise, the MFMA match, rank, fill, merge -- in which
+    everything but the match is a short latency-bound kernel; the videos are dealt out to `streams` side streams (forked from and joined
+    back into the current stream with events, nothing synchronises the host) so that the short kernels of one video run in the shadow of
+    another video's match.  Returns a list of (features, token_idx)."""
+    if not videos:
+        return []
+    if tome_ver != "video":
+        return [get_tome_features(v, prune_ratio, tome_ver, n_head) for v in videos]
+    dev = videos[0].device
+    if not all(v.is_cuda and v.device == dev for v in videos):
+        raise RuntimeError("sttm_amd runs on the GPU only: every video must be a CUDA (ROCm) tensor on one device; there is no CPU fallback")
+    ns = max(1, min(int(streams), len(videos)))
+    if ns == 1:
+        return [_tome_video(v, prune_ratio, n_head) for v in videos]
+    with torch.cuda.device(dev):
+        pool = _side_streams.setdefault(dev.index, [])
+        while len(pool) < ns:
+            pool.append(torch.cuda.Stream(device=dev))
+        cur = torch.cuda.current_stream(dev)
+        fork = torch.cuda.Event()
+        fork.record(cur)
+        out = [None] * len(videos)
+        for k in range(ns):
+            pool[k].wait_event(fork)
+        for j, v in enumerate(videos):
+            st = pool[j % ns]
+            with torch.cuda.stream(st):
+                x, idx = _tome_video(v, prune_ratio, n_head)
+            # the results are handed to the caller's stream: the caching allocator must not recycle them for the side stream first
+            x.record_stream(cur)
+            idx.record_stream(cur)
+            out[j] = (x, idx)
+        for k in range(ns):
+            done = torch.cuda.Event()
+            done.record(pool[k])
+            cur.wait_event(done)
+    return out

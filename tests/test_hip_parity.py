@@ -1095,6 +1095,26 @@ def test_tome_tile128_and_tile256_kernels_are_bit_identical(dtype):
         _lib.configure(tome_split=1)
 
 
+def test_tome_batch_over_side_streams_equals_per_video_calls():
+    """get_tome_features_batch (videos dealt out to side streams, fork / join with events) returns what per-video calls return, bit for bit,
+    for mixed shapes, dtypes and ratios with one, two and three merge iterations; repeated so that recycled scratch would show."""
+    from sttm_amd import get_tome_features, get_tome_features_batch
+    from sttm_amd.synth import synth_video
+    dev = _dev()
+    vids = [synth_video(T, C, 14, 14, seed=600 + i, dtype=dt).to(dev)
+            for i, (T, C, dt) in enumerate([(16, 256, torch.float32), (40, 128, torch.bfloat16), (8, 1024, torch.float32), (33, 64, torch.float16),
+                                            (16, 256, torch.float32), (64, 128, torch.float32), (5, 512, torch.bfloat16)])]
+    for ratio in (0.5, 0.7, 0.85):
+        single = [get_tome_features(v, ratio, "video") for v in vids]
+        for rep in range(3):
+            for ns in (2, 3):
+                batch = get_tome_features_batch(vids, ratio, "video", streams=ns)
+                torch.cuda.synchronize()
+                for (f, i), (ef, ei) in zip(batch, single):
+                    assert torch.equal(i, ei) and torch.equal(f.view(torch.uint8), ef.view(torch.uint8))
+    assert get_tome_features_batch([], 0.5) == [] and get_tome_features_batch(vids[:2], 0.5, "snippet") == [None, None]
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_tome_rank_by_counting_and_radix_sort_paths_are_bit_identical(dtype):
     """`argsort(node_max, descending)` with ties to the smaller index is computed either by counting in one kernel (`tome_rank = 0`, the
