@@ -5,6 +5,10 @@
 
 #include <type_traits>
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libsttm_hip is written for gfx950 (MI355X) only: wave64, the gfx950 MFMA / permlane-swap / LDS-DMA instructions and the sc1 hand-off forms its kernels rely on"
+#endif
+
 namespace sttm {
 
 constexpr int kMaxLevels = 6;   // deepest pyramid the fused spatial kernel supports (root .. leaf): root cells of up to 32 x 32 leaves

@@ -877,6 +877,12 @@ __global__ void __launch_bounds__(RK_I) k_tome_rank(const unsigned long long* __
         }
         __syncthreads();
     }
+    // Ordering contract of this hand-off (round-4 advisor note): it is NOT the HIP memory model's release / acquire but the gfx950 form
+    // MI355X_MICROARCH.md lists as valid ("handoff-flag: sc1 payload -> asm s_waitcnt vmcnt(0) -> sc1 flag", consumer side sc1 loads): the
+    // agent-scope relaxed stores / loads below compile to global_store / global_load ... sc1 (write-through to / read from the device's
+    // coherence point, past the CU's L1 and the XCD's L2 copy), the drain makes the payload leave before the arrival atomic, which is a
+    // memory-side read-modify-write.  The library is built for gfx950 only (sttm_common.h refuses any other device target);
+    // test_tome_rank_by_counting_and_radix_sort_paths_are_bit_identical compares this kernel with the radix-sort path.
     // Everything that crosses workgroups here is an agent-scope atomic (performed at the device's coherence point) read back with
     // agent-scope loads: every wave drains its own (vmcnt), then ONE relaxed arrival -- no release / acquire fences, which on this
     // multi-XCD part are L2 write-backs + invalidates per workgroup (a __threadfence() here made the kernel 67 - 120 us).
