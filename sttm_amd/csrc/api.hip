@@ -525,23 +525,30 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
 // on first use and kept for the life of the thread (HIP may already be gone when thread-locals are destroyed at exit: never freed).
 constexpr int kSideMax = 8;
 struct SidePool { int dev; int n; hipStream_t s[kSideMax]; hipEvent_t fork; hipEvent_t join[kSideMax]; };
+// the calling thread's pool for the current device with at least `want` streams (grown on demand); nullptr if HIP refuses
 SidePool* side_pool(int want) {
     thread_local SidePool pools[4] = {};
     thread_local int n_pools = 0;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     if (want > kSideMax) want = kSideMax;
+    SidePool* p = nullptr;
     for (int i = 0; i < n_pools; ++i)
-        if (pools[i].dev == dev && pools[i].n >= want) { static thread_local SidePool view; view = pools[i]; view.n = want; return &view; }
-    if (n_pools >= 4) return nullptr;
-    SidePool p = {};
-    p.dev = dev; p.n = want;
-    if (hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
-    for (int i = 0; i < want; ++i)
-        if (hipStreamCreateWithFlags(&p.s[i], hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&p.join[i], hipEventDisableTiming) != hipSuccess) return nullptr;
-    pools[n_pools] = p;
-    return &pools[n_pools++];
+        if (pools[i].dev == dev) p = &pools[i];
+    if (!p) {
+        if (n_pools >= 4) return nullptr;
+        p = &pools[n_pools];
+        *p = SidePool{};
+        p->dev = dev;
+        if (hipEventCreateWithFlags(&p->fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+        ++n_pools;
+    }
+    while (p->n < want) {
+        if (hipStreamCreateWithFlags(&p->s[p->n], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&p->join[p->n], hipEventDisableTiming) != hipSuccess) return nullptr;
+        ++p->n;
+    }
+    return p;
 }
 
 }  // namespace
@@ -683,7 +690,8 @@ int sttm_quadtree_merge_batch(int n_videos, const void* const* x, int64_t stride
     // marches all videos through one kernel at a time.  Same kernels, same per-video arguments: bit-identical outputs.
     SidePool* pool = (cfg.batch_streams >= 2 && n_videos >= 2) ? side_pool(cfg.batch_streams) : nullptr;
     if (pool) {
-        const int S = pool->n < n_videos ? pool->n : n_videos;
+        const int want = cfg.batch_streams < kSideMax ? cfg.batch_streams : kSideMax;
+        const int S = want < n_videos ? want : n_videos;
         const int sub = cfg.batch_sub < 1 ? 1 : (cfg.batch_sub > STTM_BATCH_MAX ? STTM_BATCH_MAX : cfg.batch_sub);
         mark(events, 0, stream);
         hipError_t e = hipEventRecord(pool->fork, stream);
