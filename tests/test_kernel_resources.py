@@ -35,6 +35,7 @@ NO_SCRATCH = [
     ("K5 bf16", r"k_group_meanINS_6bf16_tELi8ELi6E"),
     ("K5 on root cells of 17-64 leaves (C4 grids): two member rows in flight", r"k_group_meanIfLi8ELi5ELb1ELb0E"),
     ("K5 on root cells of more than 64 leaves: long groups by the whole workgroup", r"k_group_meanIfLi8ELi4ELb1ELb1E"),
+    ("K1 on the unpooled token map (get_2dPool fused into the leaf load), fp32 C<=1024", r"k_spatial_pooledIfLi4ELi256E"),
     ("ToMe 256-tile match, fp32 two-plane", r"k_tome_match_gldsILi2ELi4E"),
     ("ToMe 256-tile match, one plane", r"k_tome_match_gldsILi1ELi1E"),
 ]
