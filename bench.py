@@ -36,6 +36,8 @@ L3_BYTES = 256e6             # Infinity Cache: pools of the timed legs are sized
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA = the fp32 vector rate
 MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/FP16 MFMA, dense (32x32x16)
 KERNELS = ["quadtree_spatial", "temporal_pairs_labels", "labels_standalone", "group_mean"]
+# fp16 product terms per fp32 ToMe score (the library's tome_split switch: 2 -> three terms, the default; 1 -> four)
+TOME_TERMS = {"1": 4, "2": 3, "3": 4, "4": 4, "5": 3, "6": 3}.get(os.environ.get("STTM_TOME_SPLIT", "2"), 4)
 
 
 def parse():
@@ -230,7 +232,7 @@ def run_configs(dev, rank, world, timed, log):
     T, C, H, W = 180, 1024, 14, 14
     n_tok = T * H * W
     flops = 2.0 * ((n_tok + 1) // 2) * (n_tok // 2) * C
-    for dtn, peak in (("float32", MFMA_F16_PEAK_TFLOPS / 4.0), ("bfloat16", MFMA_F16_PEAK_TFLOPS)):
+    for dtn, peak in (("float32", MFMA_F16_PEAK_TFLOPS / TOME_TERMS), ("bfloat16", MFMA_F16_PEAK_TFLOPS)):
         pool = [synth_video(T, C, H, W, seed=7100 + i, dtype=getattr(torch, dtn), device=dev, gen_device=dev) for i in range(2)]
         get_tome_features(pool[0], 0.5, "video")
         reps = 12
@@ -419,9 +421,9 @@ def main():
         tome_vps = timed(run_tome, NT)
         n_tok = T * H * W
         flops = 2.0 * ((n_tok + 1) // 2) * (n_tok // 2) * C
-        # the match computes every fp32 score from 4 fp16 MFMA products (two-plane split, csrc/tome.hip): the bound is the fp16
-        # dense MFMA peak over 4 instructions per fp32 product
-        tome_peak = MFMA_F16_PEAK_TFLOPS / 4.0
+        # the match computes every fp32 score from TOME_TERMS fp16 MFMA products (two-plane split, csrc/tome.hip; 3 by default since
+        # round 5, 4 with tome_split = 1): the bound is the fp16 dense MFMA peak over that many instructions per fp32 product
+        tome_peak = MFMA_F16_PEAK_TFLOPS / TOME_TERMS
         ext["tome_extension"] = {
             "value": round(tome_vps, 2), "unit": "videos/s", "config": f"ToMe video r=0.5, T={T} 14x14x1024 fp32",
             "roofline": {"bound": "mfma", "achieved": round(flops * tome_vps / world / 1e12, 2), "peak": tome_peak,
@@ -429,7 +431,7 @@ def main():
                          "flops_per_video": flops,
                          "x_fp32_mfma_peak": round(flops * tome_vps / world / 1e12 / MFMA_F32_PEAK_TFLOPS, 3),
                          "note": "whole get_tome_features call (normalise + match + sort + merge) over the match's ALGORITHMIC fp32 flops; "
-                                 "peak = 2500 TFLOP/s fp16 dense MFMA / 4 product terms per fp32 score; x_fp32_mfma_peak = the same rate "
+                                 f"peak = 2500 TFLOP/s fp16 dense MFMA / {TOME_TERMS} product terms per fp32 score (rounds 2-4 ran 4 terms: bound 625); x_fp32_mfma_peak = the same rate "
                                  "over the 157.3 TFLOP/s fp32-input MFMA peak (round 1's kernel)"}}
         # the same clips as bfloat16 hidden states (what the reference's hook hands over in production): one bf16 MFMA per product
         xb = [pool[v % P].to(torch.bfloat16) for v in range(min(P, 4))]

@@ -244,12 +244,12 @@ int sttm_quadtree_merge_batch(int n_videos, const void* const* x, int64_t stride
  *   "force_gmem_labels"  1: label stage on global scratch instead of LDS (the path of columns too large for LDS)
  *   "batch_streams" / "batch_sub"   sttm_quadtree_merge_batch: internal streams (default 3; <= 1 = lockstep form) and videos per launch
  *                 set on a stream (default 8, at most STTM_BATCH_MAX)
- *   "tome_split"  ToMe match kernel for float32 inputs.  1 (default): unit rows as two fp16 planes (h + l of 4096 v, residual
- *                 <= 2^-23), scores from the products l.l + l.h + h.l + h.h on the fp16 matrix pipe with fp32 accumulation
- *                 (each product exact; error bound 2.4e-7 + the fp32 accumulation, measured <= 9.2e-7 against float64 where
- *                 the fp32-input MFMA kernel measures 1.4e-6), kernel picked by size; 2: the same without l.l (bound 4.8e-7);
- *                 0: fp32-input MFMA (v_mfma_f32_32x32x2_f32), 2.9x slower; 3 / 4: force the 128-tile / 256-tile kernel, 5 / 6
- *                 the same with three terms (tests)
+ *   "tome_split"  ToMe match kernel for float32 inputs: unit rows as two fp16 planes (h + l of 4096 v, residual <= 2^-23), scores from
+ *                 products of the planes on the fp16 matrix pipe with fp32 accumulation (each product exact).  2 (default since round 5):
+ *                 l.h + h.l + h.h -- error bound 4.8e-7 + the fp32 accumulation that every sgemm has; measured against float64 on the
+ *                 128-frame clip 9.1e-7, the same as with four terms and below the fp32-input MFMA kernel's 1.4e-6; 20 % fewer MFMAs;
+ *                 1: the same plus l.l (bound 2.4e-7 + accumulation); kernel picked by size in both; 0: fp32-input MFMA
+ *                 (v_mfma_f32_32x32x2_f32), 2.9x slower; 3 / 4: force the 128-tile / 256-tile kernel with four terms, 5 / 6 with three (tests)
  *   "tome_flat"   256-tile ToMe match kernels: 1 (default) spread all tile products evenly over one workgroup per CU when that
  *                 shortens the per-CU critical path against the best per-a-tile split (69 x 69 tiles at T = 180: 19 instead of 23
  *                 products per workgroup), 0 never, 2 always.  Same scores, same first-maximum argmax.

@@ -48,7 +48,7 @@ Config& config() {
         d.fold_labels = env_int("STTM_FOLD_LABELS", 0);
         d.no_fuse = env_int("STTM_NO_FUSE", env_int("STTM_NO_FUSE_LABELS", 0));
         d.force_gmem_labels = env_int("STTM_FORCE_GMEM_LABELS", 0);
-        d.tome_split = env_int("STTM_TOME_SPLIT", 1);
+        d.tome_split = env_int("STTM_TOME_SPLIT", 2);
         d.tome_flat = env_int("STTM_TOME_FLAT", 1);
         d.tome_rank = env_int("STTM_TOME_RANK", 0);
         d.batch_streams = env_int("STTM_BATCH_STREAMS", 3);

@@ -892,6 +892,7 @@ def test_tome_match_scores_against_dense_reference():
     assert agree > 0.999
 
 
+TOME_DEFAULT_SPLIT = 2        # the library's default (three product terms; 1 = four terms)
 TOME_MATCH_MODES = {"fp32_mfma": 0, "split4_tile128": 3, "split4_tile256_dma": 4, "split3_tile128": 5, "split3_tile256_dma": 6}
 
 
@@ -945,7 +946,7 @@ def test_tome_match_kernel_variants(mode):
             print(f"{mode} T={T}: max |best score - float64| {err:.3e}, argmax agreement {agree:.5f}")
             assert err < 2e-6 and agree > 0.999
     finally:
-        _lib.configure(tome_split=1)
+        _lib.configure(tome_split=TOME_DEFAULT_SPLIT)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
@@ -1000,7 +1001,7 @@ def test_tome_first_maximum_on_exact_ties(dtype):
                 assert bad.numel() == 0, (f"{dtype} na={na} tome_split={mode} tome_flat={flat}: {bad.numel()} rows did not take the first of their tied "
                                           f"candidates, e.g. row {int(bad[0])}: got {int(got[bad[0]])}, first copy {int(want[bad[0]])}")
     finally:
-        _lib.configure(tome_split=1, tome_flat=1)
+        _lib.configure(tome_split=TOME_DEFAULT_SPLIT, tome_flat=1)
 
 
 def test_tome_fuzz_against_oracle():
@@ -1043,7 +1044,7 @@ def test_tome_fuzz_against_oracle():
         print(f"tome fuzz: {exact} exact, {near} near-tie")
         assert exact >= 25
     finally:
-        _lib.configure(tome_split=1, tome_flat=1)
+        _lib.configure(tome_split=TOME_DEFAULT_SPLIT, tome_flat=1)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
@@ -1068,7 +1069,7 @@ def test_tome_flat_and_per_tile_work_splits_are_bit_identical(dtype):
             for flat, (f, i) in zip((2, 1), outs[1:]):
                 assert torch.equal(i, outs[0][1]) and torch.equal(f, outs[0][0]), f"{dtype} T={T} C={C} r={ratio}: tome_flat {flat} differs from 0"
     finally:
-        _lib.configure(tome_split=1, tome_flat=1)
+        _lib.configure(tome_split=TOME_DEFAULT_SPLIT, tome_flat=1)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
@@ -1092,7 +1093,7 @@ def test_tome_tile128_and_tile256_kernels_are_bit_identical(dtype):
                 fb, ib = get_tome_features(x, ratio, "video")
                 assert torch.equal(ia, ib) and torch.equal(fa, fb), f"{dtype} T={T} C={C} r={ratio}: kernels {small} / {big} differ"
     finally:
-        _lib.configure(tome_split=1)
+        _lib.configure(tome_split=TOME_DEFAULT_SPLIT)
 
 
 def test_tome_batch_over_side_streams_equals_per_video_calls():
@@ -1175,7 +1176,7 @@ def test_tome_16bit_match_kernel_variants(mode):
             ida, fa = _tome16_agreement(f, i, ef, ei, f"{mode} {dtype}")
             _assert_tome16(ida, fa, ei.numel(), f"{mode} {dtype}")
     finally:
-        _lib.configure(tome_split=1)
+        _lib.configure(tome_split=TOME_DEFAULT_SPLIT)
 
 
 @pytest.mark.parametrize("case", [c for c in kat()["errors"] if c["fn"] == "tome"], ids=lambda c: c["name"])
