@@ -61,3 +61,38 @@ def test_fuzz_against_oracle(case):
         assert float(err.max()) <= 1e-5
     else:
         assert float((err / ef.float().abs().clamp_min(1.0)).max()) <= 2 ** -7
+
+
+@pytest.mark.parametrize("chunk", range(6))
+def test_fuzz_through_the_batch_entry_point(chunk):
+    """The same random cases (every 3rd one: shapes, dtypes, root levels, weighted / slow variants mixed) through
+    get_quadtree_features_batch -- several differently shaped videos per call, each shape twice, so launch sets of several videos form --
+    must equal the one-video calls bit for bit (launch sets run 8 group-mean workgroups per frame and 256-thread label columns: neither may
+    change a result)."""
+    from sttm_amd import get_quadtree_features, get_quadtree_features_batch
+    from sttm_amd.synth import iid_video, synth_video
+    dev = torch.device("cuda:0")
+    cases = _cases(180, 4321)[chunk::6][::1][:30]
+    by_params = {}
+    for c in cases:
+        by_params.setdefault((c[5], c[6], c[7], c[8], c[9]), []).append(c)          # one batch call per (root, thr, tthr, weighted, slow)
+    for (root, thr, tthr, weighted, slow), group in by_params.items():
+        vids = []
+        for (T, C, H, W, dtype, _, _, _, _, _, kind, seed) in group:
+            for s in (seed, seed + 1):
+                if kind == "iid":
+                    vids.append(iid_video(T, C, H, W, seed=s, dtype=dtype).to(dev))
+                else:
+                    kw = dict(c=0.15, p_static=0.7) if kind == "smooth" else {}
+                    vids.append(synth_video(T, C, H, W, seed=s, dtype=dtype, **kw).to(dev))
+        try:
+            single = [get_quadtree_features(v, thr, tthr, root, weighted, slow_ver=slow) for v in vids]
+        except (IndexError, RuntimeError, NotImplementedError) as e:
+            with pytest.raises(type(e)):
+                get_quadtree_features_batch(vids, thr, tthr, root, weighted, slow_ver=slow)
+            continue
+        batch = get_quadtree_features_batch(vids, thr, tthr, root, weighted, slow_ver=slow)
+        torch.cuda.synchronize()
+        for k, (b, s_) in enumerate(zip(batch, single)):
+            for u, v in zip(b, s_):
+                assert u.shape == v.shape and torch.equal(u.view(torch.uint8), v.view(torch.uint8)), (root, thr, tthr, weighted, slow, k)
