@@ -14,8 +14,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsttm_hip.so")
 SOURCES = ["quadtree_spatial.hip", "spatial_f32.hip", "spatial_bf16.hip", "spatial_f16.hip", "spatial_f32_head.hip",
-           "spatial_bf16_head.hip", "spatial_f16_head.hip", "spatial_pooled_f32.hip", "spatial_pooled_bf16.hip", "spatial_pooled_f16.hip", "temporal_merge.hip", "tome.hip", "pool2d.hip", "dycoke.hip", "octree.hip", "api.hip"]
-HEADERS = ["sttm_common.h", "sttm_kernels.h", "sttm_pairs.inc", "quadtree_spatial.inc", "spatial_pooled.inc", os.path.join("..", "..", "include", "sttm_hip.h")]
+           "spatial_bf16_head.hip", "spatial_f16_head.hip", "spatial_pooled_f32.hip", "spatial_pooled_bf16.hip", "spatial_pooled_f16.hip",
+           "spatial_col_f32.hip", "spatial_col_bf16.hip", "spatial_col_f16.hip", "temporal_merge.hip", "tome.hip", "pool2d.hip", "dycoke.hip", "octree.hip", "api.hip"]
+HEADERS = ["sttm_common.h", "sttm_kernels.h", "sttm_pairs.inc", "quadtree_spatial.inc", "spatial_pooled.inc", "spatial_col.inc", os.path.join("..", "..", "include", "sttm_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 if os.environ.get("STTM_NT_STREAM") == "1":
     FLAGS.append("-DSTTM_NT_STREAM")
@@ -67,6 +68,7 @@ def build(force=False, verbose=False, extra_flags=(), dev=False):
     common = [os.path.join(CSRC, h) for h in HEADERS if not h.endswith(".inc")]
     # the two big template files are included by some translation units only
     inc_users = {"quadtree_spatial.inc": lambda src: src.startswith("spatial_"), "spatial_pooled.inc": lambda src: src.startswith("spatial_pooled_"),
+                 "spatial_col.inc": lambda src: src.startswith("spatial_col_"),
                  "sttm_pairs.inc": lambda src: src == "temporal_merge.hip"}
 
     def deps(src):

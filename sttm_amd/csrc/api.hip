@@ -25,7 +25,7 @@ int fail(int code, const char* fmt, ...) {
 // None of them changes results.
 struct Config {
     int pairs_seg, pairs_nt, pairs_var, k1_var, k1_split, no_dense, gm_split, label_nt, vec16, vec32, fold_kb, fold_labels, no_fuse, force_gmem_labels, tome_split, tome_flat, tome_rank,
-        batch_streams, batch_sub;
+        batch_streams, batch_sub, col_walk, col_frames, col_cap, col_pb, col_abl, pair_vec;
 };
 int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
@@ -53,6 +53,14 @@ Config& config() {
         d.tome_rank = env_int("STTM_TOME_RANK", 0);
         d.batch_streams = env_int("STTM_BATCH_STREAMS", 3);
         d.batch_sub = env_int("STTM_BATCH_SUB", 8);
+        // the column-walk spatial stage (spatial_col.inc): 0 = never (default: measured slower than the spatial + pair kernels although it
+        // moves 17 % fewer bytes -- DESIGN.md 4.5), 1 = launch sets of several videos, 2 = also a single video (tests / A-B)
+        d.col_walk = env_int("STTM_COL_WALK", 0);
+        d.col_frames = env_int("STTM_COL_FRAMES", 8);
+        d.col_cap = env_int("STTM_COL_CAP", 0);            // 0 = what the LDS budget allows
+        d.col_pb = env_int("STTM_COL_PB", 0);
+        d.col_abl = env_int("STTM_COL_ABL", 0);
+        d.pair_vec = env_int("STTM_PAIR_VEC", 0);          // 0 = the column walk's width where it could run (see merge_group); -1 = the row kernels' width (rounds 1-5)
         return d;
     }();
     return c;
@@ -426,6 +434,32 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
     ta.T = T; ta.H = H; ta.W = W; ta.C = C; ta.R = p.R;
     ta.dims = p.dims;
     ta.dtype = dtype; ta.vec = row_vec(C, dtype, vec, dense, all_bits % 32 == 0, head_dim);
+    // The column-walk spatial stage (spatial_col.inc, opt-in: col_walk) forms the pair stage's dot products itself; it covers the production
+    // shape -- 3-level trees, whole-vector cosine, the fast pair filter, 16-byte packs of rows of at most 512 lanes -- and is meant for
+    // launch sets of several videos (one video has too few columns to fill the device).  So that both forms give the same bits, the pair
+    // kernel of such a shape sums in the column walk's order: the spatial kernel's 16-byte packs.
+    sttm::ColWalkArgs cw;
+    memset(&cw, 0, sizeof(cw));
+    const int vec16 = 16 / (int)elem_bytes(dtype);
+    bool col_shape = !nodes && !pool && p.dims.n_level == 3 && head_dim == 0 && !slow_ver && temporal_thresh > 0.f && T > 1 &&
+                     vec * (int)elem_bytes(dtype) >= 16 && C % vec16 == 0 && (C / vec16 + 63) / 64 * 64 <= 512;
+    int col_nt = 0;
+    if (col_shape) {
+        col_nt = (C / vec16 + 63) / 64 * 64;
+        const size_t budget = (col_nt <= 256 ? 53 : 80) * 1024;                 // three (two) workgroups per CU
+        cw.pb = cfg.col_pb > 0 ? cfg.col_pb : (col_nt <= 256 ? 10 : 6);
+        if (cw.pb > 16) cw.pb = 16;
+        const size_t fixed = sttm::col_walk_lds_bytes(col_nt, 0, cw.pb);
+        int cap = fixed < budget ? (int)((budget - fixed) / ((size_t)col_nt * 16)) : 0;
+        if (cap > 16) cap = 16;
+        if (cfg.col_cap > 0 && cfg.col_cap < cap) cap = cfg.col_cap;
+        cw.cap = cap;
+        cw.frames = cfg.col_frames > 0 ? cfg.col_frames : 8;
+        cw.abl = cfg.col_abl;
+        if (cap < 4 && cfg.col_cap <= 0) col_shape = false;
+    }
+    const bool col_walk = col_shape && (cfg.col_walk >= 2 || (cfg.col_walk == 1 && nv > 1));
+    ta.pair_vec = cfg.pair_vec > 0 ? cfg.pair_vec : ((col_shape && cfg.pair_vec == 0) ? vec16 : ta.vec);
     sttm::pairs_shape(T, p.R, cfg.fold_labels && !slow_ver, cfg.pairs_seg, cfg.pairs_nt, &ta.pairs_seg, &ta.pairs_nt);
     ta.pairs_var = cfg.pairs_var;
     // threads per label column: 1024 for one video (the stage is the call's critical path), 256 in launch sets of several videos (the
@@ -468,7 +502,7 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
 
     const bool pairs = ta.temporal_on && T > 1;
     int fold_cap = 0;
-    ta.fold_labels = (pairs && sttm::labels_can_fold(ta, nv, &fold_cap)) ? 1 : 0;
+    ta.fold_labels = (pairs && !col_walk && sttm::labels_can_fold(ta, nv, &fold_cap)) ? 1 : 0;
     ta.fold_cap = fold_cap;
 
     hipError_t e;
@@ -487,6 +521,10 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
     } else if (pool) {
         if ((e = sttm::launch_spatial_pooled(sa, bp, nv, dtype, nt, stream)) != hipSuccess)
             return fail(STTM_ERR_LAUNCH, "spatial kernel (pooled input): %s", hipGetErrorString(e));
+    } else if (col_walk) {
+        cw.edges = ta.edges; cw.edge_cnt = ta.edge_cnt; cw.cand_cnt = ta.cand_cnt; cw.ecap = ta.ecap; cw.temporal_thresh = temporal_thresh;
+        if ((e = sttm::launch_spatial_col(sa, bp, cw, nv, dtype, col_nt, stream)) != hipSuccess)
+            return fail(STTM_ERR_LAUNCH, "spatial kernel (column walk): %s", hipGetErrorString(e));
     } else if ((e = sttm::launch_spatial(sa, bp, nv, dtype, vec, nt, stream, tops)) != hipSuccess)
         return fail(STTM_ERR_LAUNCH, "spatial kernel: %s", hipGetErrorString(e));
     mark(events, 1, stream);
@@ -496,7 +534,7 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
         return STTM_OK;
     }
 #endif
-    if (pairs) {
+    if (pairs && !col_walk) {
         if ((e = sttm::launch_pairs(ta, bp, nv, stream)) != hipSuccess)
             return fail(STTM_ERR_LAUNCH, "pairs kernel: %s", hipGetErrorString(e));
     }
@@ -575,6 +613,7 @@ int sttm_configure(const char* key, int value) {
         {"pairs_seg", &c.pairs_seg}, {"pairs_nt", &c.pairs_nt}, {"pairs_var", &c.pairs_var}, {"k1_var", &c.k1_var}, {"k1_split", &c.k1_split}, {"no_dense", &c.no_dense}, {"gm_split", &c.gm_split}, {"label_nt", &c.label_nt},
         {"vec16", &c.vec16}, {"vec32", &c.vec32}, {"fold_kb", &c.fold_kb}, {"fold_labels", &c.fold_labels}, {"no_fuse", &c.no_fuse}, {"tome_split", &c.tome_split}, {"tome_flat", &c.tome_flat}, {"tome_rank", &c.tome_rank},
         {"force_gmem_labels", &c.force_gmem_labels}, {"batch_streams", &c.batch_streams}, {"batch_sub", &c.batch_sub},
+        {"col_walk", &c.col_walk}, {"col_frames", &c.col_frames}, {"col_cap", &c.col_cap}, {"col_pb", &c.col_pb}, {"col_abl", &c.col_abl}, {"pair_vec", &c.pair_vec},
     };
     for (auto& k : keys)
         if (!strcmp(key, k.name)) { *k.slot = value; return STTM_OK; }

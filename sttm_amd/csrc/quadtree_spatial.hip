@@ -28,6 +28,16 @@ hipError_t launch_spatial_pooled(const SpatialArgs& a, const BatchPtrs& bp, int 
     return hipErrorInvalidValue;
 }
 
+template <typename T>
+hipError_t launch_spatial_col_t(const SpatialArgs& a, const BatchPtrs& bp, const ColWalkArgs& cw, int n_videos, int nt, hipStream_t stream);
+
+hipError_t launch_spatial_col(const SpatialArgs& a, const BatchPtrs& bp, const ColWalkArgs& cw, int n_videos, int dtype, int nt, hipStream_t stream) {
+    if (dtype == STTM_F32) return launch_spatial_col_t<float>(a, bp, cw, n_videos, nt, stream);
+    if (dtype == STTM_BF16) return launch_spatial_col_t<bf16_t>(a, bp, cw, n_videos, nt, stream);
+    if (dtype == STTM_F16) return launch_spatial_col_t<f16_t>(a, bp, cw, n_videos, nt, stream);
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_node_apply(const SpatialArgs& a, int dtype, int vec, int nt, hipStream_t stream) {
     if (dtype == STTM_F32) return launch_apply_t<float>(a, vec, nt, stream);
     if (dtype == STTM_BF16) return launch_apply_t<bf16_t>(a, vec, nt, stream);

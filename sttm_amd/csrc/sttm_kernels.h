@@ -101,6 +101,26 @@ inline size_t split_ufeat_bytes(int T, const LevelDims& d, int C, int elem_bytes
 // whole-vector cosine only); tops = [T][h_block_level][w_block_level][C] elements of the input dtype per video, inside the workspace
 hipError_t launch_spatial(const SpatialArgs& a, const BatchPtrs& bp, int n_videos, int dtype, int vec, int nt, hipStream_t stream, void* tops = nullptr);
 hipError_t launch_node_apply(const SpatialArgs& a, int dtype, int vec, int nt, hipStream_t stream);
+// The column-walk spatial stage (spatial_col.inc, round 6; launch sets of several videos): one workgroup per (root cell, chunk of
+// `frames` frames) that also runs the pair stage on rows kept in LDS.  The pointers are TemporalArgs' (video 0; shifted per video).
+struct ColWalkArgs {
+    int32_t* edges;           // [R][T-1][ecap]
+    int32_t* edge_cnt;        // [R][T-1]
+    int32_t* cand_cnt;        // [R][T-1]
+    int ecap;
+    float temporal_thresh;
+    int frames;               // frames per workgroup (a chunk that does not start the clip reads one warm-up frame more)
+    int cap;                  // node rows of the frame before kept in LDS (the rest is re-read from S / x)
+    int pb;                   // candidate pairs per round of partial products
+    int abl;                  // ablation bits for measurements (outputs invalid): 1 = no pair phase, 2 = no row stash, 4 = no warm-up frame
+};
+constexpr int kColStatRow = 44;       // floats per wave of the statistics table (TreeConst<3>::NSTAT, checked in spatial_col.inc)
+// LDS of a column-walk workgroup (spatial_col.inc carves it in this order): node rows | 2 x 16 inverse norms, 2 x 16 + 16 pair descriptors,
+// 2 (+ 2) edge counters | partial dot products | per-wave statistics
+inline size_t col_walk_lds_bytes(int nt, int cap, int pb) {
+    return (size_t)cap * nt * 16 + sizeof(double) * 64 + sizeof(int) * 20 + sizeof(float) * ((size_t)pb * nt + (size_t)(nt / 64) * kColStatRow);
+}
+hipError_t launch_spatial_col(const SpatialArgs& a, const BatchPtrs& bp, const ColWalkArgs& cw, int n_videos, int dtype, int nt, hipStream_t stream);
 // 3-level trees, 16-byte packs, whole-vector cosine: the spatial stage reading the unpooled token map (a.src_h x a.src_w, a.pool_mode)
 hipError_t launch_spatial_pooled(const SpatialArgs& a, const BatchPtrs& bp, int n_videos, int dtype, int nt, hipStream_t stream);      // (pooled grid side <= kPoolMaxSide)
 
@@ -108,6 +128,7 @@ struct TemporalArgs {
     int T, H, W, C, R;        // R = root cells per frame
     LevelDims dims;
     int dtype, vec;
+    int pair_vec;             // pack width of the pair kernel (the order its dot products are summed in; = the column walk's where that can run)
     float temporal_thresh;    // cosine threshold of the pair filter
     int temporal_on;          // 0: no temporal stage (labels stay the identity).  The merge: temporal_thresh > 0 (quadtree_builder.py:217);
                               // the stand-alone temporal stage: always (cross_frame_node_merging_fast filters with whatever threshold it is given)

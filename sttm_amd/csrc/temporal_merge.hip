@@ -1058,21 +1058,21 @@ hipError_t launch_pairs(const TemporalArgs& a, const BatchPtrs& bp, int n_videos
     // 32.8 -> 27.7 us; variants bounded to 6 / 8 waves spilled and were slower).  pairs_var = 9 selects the general kernel.
     if (nt == 256 && a.pairs_var != 9 && !a.fold_labels && a.n_head == 0) {
         if (a.dtype == STTM_F32) {
-            if (a.vec == 8) STTM_LAUNCH_PAIRS256(float, 8, 5, 32); else if (a.vec == 4) STTM_LAUNCH_PAIRS256(float, 4, 5, 32);
-            else if (a.vec == 2) STTM_LAUNCH_PAIRS256(float, 2, 5, 32); else STTM_LAUNCH_PAIRS256(float, 1, 5, 32);
+            if (a.pair_vec == 8) STTM_LAUNCH_PAIRS256(float, 8, 5, 32); else if (a.pair_vec == 4) STTM_LAUNCH_PAIRS256(float, 4, 5, 32);
+            else if (a.pair_vec == 2) STTM_LAUNCH_PAIRS256(float, 2, 5, 32); else STTM_LAUNCH_PAIRS256(float, 1, 5, 32);
         } else if (a.dtype == STTM_BF16) {
-            if (a.vec == 8) STTM_LAUNCH_PAIRS256(bf16_t, 8, 5, 64); else if (a.vec == 4) STTM_LAUNCH_PAIRS256(bf16_t, 4, 5, 64); else STTM_LAUNCH_PAIRS256(bf16_t, 2, 5, 64);
+            if (a.pair_vec == 8) STTM_LAUNCH_PAIRS256(bf16_t, 8, 5, 64); else if (a.pair_vec == 4) STTM_LAUNCH_PAIRS256(bf16_t, 4, 5, 64); else STTM_LAUNCH_PAIRS256(bf16_t, 2, 5, 64);
         } else {
-            if (a.vec == 8) STTM_LAUNCH_PAIRS256(f16_t, 8, 5, 64); else if (a.vec == 4) STTM_LAUNCH_PAIRS256(f16_t, 4, 5, 64); else STTM_LAUNCH_PAIRS256(f16_t, 2, 5, 64);
+            if (a.pair_vec == 8) STTM_LAUNCH_PAIRS256(f16_t, 8, 5, 64); else if (a.pair_vec == 4) STTM_LAUNCH_PAIRS256(f16_t, 4, 5, 64); else STTM_LAUNCH_PAIRS256(f16_t, 2, 5, 64);
         }
         return hipGetLastError();
     }
     if (a.dtype == STTM_F32) {
-        if (a.vec == 8) STTM_LAUNCH_PAIRS(float, 8); else if (a.vec == 4) STTM_LAUNCH_PAIRS(float, 4); else if (a.vec == 2) STTM_LAUNCH_PAIRS(float, 2); else STTM_LAUNCH_PAIRS(float, 1);
+        if (a.pair_vec == 8) STTM_LAUNCH_PAIRS(float, 8); else if (a.pair_vec == 4) STTM_LAUNCH_PAIRS(float, 4); else if (a.pair_vec == 2) STTM_LAUNCH_PAIRS(float, 2); else STTM_LAUNCH_PAIRS(float, 1);
     } else if (a.dtype == STTM_BF16) {
-        if (a.vec == 8) STTM_LAUNCH_PAIRS(bf16_t, 8); else if (a.vec == 4) STTM_LAUNCH_PAIRS(bf16_t, 4); else STTM_LAUNCH_PAIRS(bf16_t, 2);
+        if (a.pair_vec == 8) STTM_LAUNCH_PAIRS(bf16_t, 8); else if (a.pair_vec == 4) STTM_LAUNCH_PAIRS(bf16_t, 4); else STTM_LAUNCH_PAIRS(bf16_t, 2);
     } else {
-        if (a.vec == 8) STTM_LAUNCH_PAIRS(f16_t, 8); else if (a.vec == 4) STTM_LAUNCH_PAIRS(f16_t, 4); else STTM_LAUNCH_PAIRS(f16_t, 2);
+        if (a.pair_vec == 8) STTM_LAUNCH_PAIRS(f16_t, 8); else if (a.pair_vec == 4) STTM_LAUNCH_PAIRS(f16_t, 4); else STTM_LAUNCH_PAIRS(f16_t, 2);
     }
 #undef STTM_LAUNCH_PAIRS
     return hipGetLastError();
