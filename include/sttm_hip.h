@@ -15,7 +15,11 @@
  * Conventions
  *   - every pointer is a DEVICE pointer unless its name ends in _host;
  *   - the library never allocates device memory and never synchronises: the caller owns all buffers
- *     (sized with the *_workspace_bytes / worst-case rules below) and the stream;
+ *     (sized with the *_workspace_bytes / worst-case rules below) and the stream.  ONE exception: the stage-skewed form of
+ *     sttm_quadtree_merge_batch (default, "batch_streams" >= 2) runs on INTERNAL non-blocking streams -- at most 8 per host
+ *     thread and device, created on first use, forked from and joined back into the caller's stream with events, so the
+ *     caller's stream order is preserved --; they live until the thread calls sttm_release_streams() (or the process ends);
+ *     "batch_streams" <= 1 keeps every launch on the caller's stream;
  *   - return value 0 = success, < 0 = error (sttm_last_error() returns a thread-local message);
  *   - dtype codes: 0 = float32, 1 = bfloat16, 2 = float16;
  *   - strides are in ELEMENTS of the logical [T, C, H, W] tensor the reference API receives; the
@@ -31,7 +35,7 @@
 extern "C" {
 #endif
 
-#define STTM_ABI_VERSION 7
+#define STTM_ABI_VERSION 8
 
 #define STTM_F32 0
 #define STTM_BF16 1
@@ -244,12 +248,22 @@ int sttm_quadtree_merge_batch(int n_videos, const void* const* x, int64_t stride
  *   "force_gmem_labels"  1: label stage on global scratch instead of LDS (the path of columns too large for LDS)
  *   "batch_streams" / "batch_sub"   sttm_quadtree_merge_batch: internal streams (default 3; <= 1 = lockstep form) and videos per launch
  *                 set on a stream (default 8, at most STTM_BATCH_MAX)
+ *   "col_walk"    the column-walk spatial stage (csrc/spatial_col.inc: one workgroup per root-cell column and chunk of "col_frames"
+ *                 frames that also runs the pair stage on node rows kept in LDS; 3-level trees, whole-vector cosine, fast pair filter):
+ *                 0 (default) never -- it moves 17 % fewer bytes and is slower --, 1 launch sets of several videos,
+ *                 2 also one-video calls (tests).  "col_frames" (8), "col_cap" / "col_pb" (0 = what the LDS budget allows) shape it.
+ *                 Bit-identical outputs in every setting.
+ *   "pair_vec"    pack width of the pair kernel = the order its dot products are summed in: 0 (default) the column walk's (the spatial
+ *                 kernel's 16-byte packs) wherever that stage could run, so that both forms give the same bits; -1 the row kernels'
+ *                 width (rounds 1-5: 8 floats); differences are confined to the last bits of a similarity that sits on the threshold.
  *   "tome_split"  ToMe match kernel for float32 inputs: unit rows as two fp16 planes (h + l of 4096 v, residual <= 2^-23), scores from
  *                 products of the planes on the fp16 matrix pipe with fp32 accumulation (each product exact).  2 (default since round 5):
  *                 l.h + h.l + h.h -- error bound 4.8e-7 + the fp32 accumulation that every sgemm has; measured against float64 on the
  *                 128-frame clip 9.1e-7, the same as with four terms and below the fp32-input MFMA kernel's 1.4e-6; 20 % fewer MFMAs;
  *                 1: the same plus l.l (bound 2.4e-7 + accumulation); kernel picked by size in both; 0: fp32-input MFMA
- *                 (v_mfma_f32_32x32x2_f32), 2.9x slower; 3 / 4: force the 128-tile / 256-tile kernel with four terms, 5 / 6 with three (tests)
+ *                 (v_mfma_f32_32x32x2_f32), 2.9x slower; 3 / 4: force the 128-tile / 256-tile kernel with four terms, 5 / 6 with three (tests);
+ *                 7: the FOUR-WAVE form of the 256-tile kernel, three terms, also for 16-bit inputs (128 x 128 wave tiles, one wave per SIMD,
+ *                 the 256 accumulators in literally named AGPRs; round 6 -- no faster than the eight-wave form)
  *   "tome_flat"   256-tile ToMe match kernels: 1 (default) spread all tile products evenly over one workgroup per CU when that
  *                 shortens the per-CU critical path against the best per-a-tile split (69 x 69 tiles at T = 180: 19 instead of 23
  *                 products per workgroup), 0 never, 2 always.  Same scores, same first-maximum argmax.
@@ -257,6 +271,11 @@ int sttm_quadtree_merge_batch(int n_videos, const void* const* x, int64_t stride
  *                 radix sort path (A/B, tests).  Same order: descending best score, ties to the smaller token index.
  */
 int sttm_configure(const char* key, int value);
+
+/* ABI v8: destroys the internal streams / events sttm_quadtree_merge_batch created for the CALLING host thread (all devices), after
+ * synchronising them; returns how many streams were released.  The next batch call creates them again.  Call it from a thread that
+ * is done with the library (thread-local state is not reachable from other threads). */
+int sttm_release_streams(void);
 
 /*
  * Position-embedding ablation (pos_embs argument of get_quadtree_features; quadtree_spatial_merger.py:88-153,
@@ -329,7 +348,7 @@ int sttm_quadtree_merge_pooled(const void* x_tokens, int T, int src_h, int src_w
                                float threshold, float temporal_thresh, int root_level, int weighted_avg, int slow_ver,
                                void* workspace, size_t workspace_bytes,
                                void* feat_out, int32_t* npatch_out, int32_t* tlbr_out, int32_t* counts,
-                               int32_t* counts_host, int seq, void* stream);
+                               int32_t* counts_host, int seq, void* stream, int flags /* ABI v8: STTM_FLAG_*, as sttm_quadtree_merge_packed */);
 
 /*
  * Nearest-neighbour resize of every frame to OH x OW: the "pyrd" baseline's F.interpolate(video, size=(s, s))

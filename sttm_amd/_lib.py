@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libsttm_hip_dev.so" if _which == "dev" el
 
 STTM_F32, STTM_BF16, STTM_F16 = 0, 1, 2
 ERR_ARG, ERR_UNSUPPORTED, ERR_LAUNCH, ERR_INDEX, ERR_PARITY, ERR_TIMEOUT = -1, -2, -3, -4, -5, -6
-ABI_VERSION = 7            # STTM_ABI_VERSION of include/sttm_hip.h this binding was written for
+ABI_VERSION = 8            # STTM_ABI_VERSION of include/sttm_hip.h this binding was written for
 CNT_NODES, CNT_CANDIDATES, CNT_EDGES, CNT_OUT, CNT_ITERS, CNT_OVERFLOW, CNT_LEAFNODES, CNT_SLOTS = 0, 1, 2, 3, 4, 5, 6, 8
 OVF_BARRIER_TIMEOUT = 64   # STTM_OVF_BARRIER_TIMEOUT
 EVENT_SLOTS = 5            # STTM_EVENT_SLOTS
@@ -39,7 +39,8 @@ SIGNATURES = {
                                        _vp, _sz, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "sttm_quadtree_merge_batch": (_i, [_i, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _f, _i, _i, _i, _i,
                                        _vp, _sz, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
-    "sttm_quadtree_merge_pooled": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "sttm_quadtree_merge_pooled": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i]),
+    "sttm_release_streams": (_i, []),
     "sttm_configure": (_i, [ctypes.c_char_p, _i]),
     "sttm_wait_counts": (_i, [_vp, _i, _i]),
     "sttm_quadtree_merge_packed": (_i, [_vp]),

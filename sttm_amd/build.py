@@ -85,6 +85,10 @@ def build(force=False, verbose=False, extra_flags=(), dev=False):
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
         extra = [f'-DSTTM_BUILD_TAG="{tag}"'] if src == "api.hip" else []
+        if src == "tome.hip":
+            # the four-wave match kernel names its accumulators (all 256 AGPRs) literally in inline assembly: the compiler must not park
+            # spilled VGPRs there
+            extra += ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"]
         # changed FLAGS rebuild every object (they apply to all of them); a changed source rebuilds the objects older than it, plus
         # api.o, which has the source + flags tag baked in (sttm_build_tag)
         if force or flags_changed or _stale(o, [s] + deps(src)) or (src == "api.hip" and old_tag != tag):

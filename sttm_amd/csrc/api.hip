@@ -345,7 +345,7 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
                 void* const* feat_out, int32_t* const* npatch_out, int32_t* const* tlbr_out, int32_t* counts,
                 int32_t* counts_host, int seq, void* const* events, hipStream_t stream,
                 uint64_t* early_host = nullptr, int* n_early = nullptr, int flags = 0, int32_t* idx_out = nullptr,
-                const NodeList* nodes = nullptr, const PoolSrc* pool = nullptr) {
+                const NodeList* nodes = nullptr, const PoolSrc* pool = nullptr, int concurrent_sets = 1) {
     if (n_early) *n_early = 0;
     if (!x || !workspace || !feat_out || !npatch_out || !tlbr_out || !counts) return fail(STTM_ERR_ARG, "null pointer argument");
     if (nodes && nv != 1) return fail(STTM_ERR_UNSUPPORTED, "the stand-alone temporal stage takes one video");
@@ -544,7 +544,9 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
     }
     mark(events, 2, stream);
     if (!ta.fold_labels) {
-        if (sttm::labels_can_fuse(ta, nv)) {
+        // (the stage-skewed batch form runs `concurrent_sets` launch sets at once, and every one of them can sit in the fused label
+        // kernel's grid barrier at the same time: the residency budget is shared between them)
+        if (sttm::labels_can_fuse(ta, nv * (concurrent_sets > 1 ? concurrent_sets : 1))) {
             if ((e = sttm::launch_labels_fused(ta, bp, nv, stream)) != hipSuccess)
                 return fail(STTM_ERR_LAUNCH, "fused label kernel: %s", hipGetErrorString(e));
         } else if ((e = sttm::launch_col_labels(ta, bp, nv, true, stream)) != hipSuccess ||
@@ -564,9 +566,11 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
 constexpr int kSideMax = 8;
 struct SidePool { int dev; int n; hipStream_t s[kSideMax]; hipEvent_t fork; hipEvent_t join[kSideMax]; };
 // the calling thread's pool for the current device with at least `want` streams (grown on demand); nullptr if HIP refuses
+thread_local SidePool g_side_pools[4] = {};
+thread_local int g_side_pool_count = 0;
 SidePool* side_pool(int want) {
-    thread_local SidePool pools[4] = {};
-    thread_local int n_pools = 0;
+    SidePool* const pools = g_side_pools;
+    int& n_pools = g_side_pool_count;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     if (want > kSideMax) want = kSideMax;
@@ -605,6 +609,28 @@ extern "C" {
 int sttm_abi_version(void) { return STTM_ABI_VERSION; }
 const char* sttm_build_tag(void) { return STTM_BUILD_TAG; }
 const char* sttm_last_error(void) { return g_err; }
+
+int sttm_release_streams(void) {
+    // the calling thread's internal streams / events of sttm_quadtree_merge_batch (all devices): synchronised, destroyed, forgotten
+    int n = 0;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (int i = 0; i < g_side_pool_count; ++i) {
+        SidePool& p = g_side_pools[i];
+        (void)hipSetDevice(p.dev);
+        for (int k = 0; k < p.n; ++k) {
+            (void)hipStreamSynchronize(p.s[k]);
+            (void)hipStreamDestroy(p.s[k]);
+            (void)hipEventDestroy(p.join[k]);
+            ++n;
+        }
+        (void)hipEventDestroy(p.fork);
+        p = SidePool{};
+    }
+    g_side_pool_count = 0;
+    (void)hipSetDevice(cur);
+    return n;
+}
 
 int sttm_configure(const char* key, int value) {
     if (!key) return fail(STTM_ERR_ARG, "null key");
@@ -696,7 +722,7 @@ int sttm_quadtree_merge_pooled(const void* x_tokens, int T, int src_h, int src_w
                                float threshold, float temporal_thresh, int root_level, int weighted_avg, int slow_ver,
                                void* workspace, size_t workspace_bytes,
                                void* feat_out, int32_t* npatch_out, int32_t* tlbr_out, int32_t* counts,
-                               int32_t* counts_host, int seq, void* stream_) {
+                               int32_t* counts_host, int seq, void* stream_, int flags) {
     if (src_h < 1 || src_w < 1 || pool_stride < 1) return fail(STTM_ERR_ARG, "bad source grid / stride");
     if (pool_mode < STTM_POOL_AVERAGE || pool_mode > STTM_POOL_BILINEAR) return fail(STTM_ERR_ARG, "Unexpected mm_spatial_pool_mode: %d", pool_mode);
     if (pool_stride == 1) return fail(STTM_ERR_ARG, "stride 1 is the identity (get_2dPool returns its input): call sttm_quadtree_merge");
@@ -707,7 +733,7 @@ int sttm_quadtree_merge_pooled(const void* x_tokens, int T, int src_h, int src_w
     const PoolSrc pool{src_h, src_w, pool_mode, pool_stride};
     return merge_group(1, &x_tokens, (int64_t)src_h * src_w * C, 1, (int64_t)src_w * C, C, T, C, H, W, dtype, threshold, temporal_thresh,
                        root_level, weighted_avg, 0, slow_ver, workspace, workspace_bytes, &feat_out, &npatch_out, &tlbr_out, counts,
-                       counts_host, seq, nullptr, reinterpret_cast<hipStream_t>(stream_), nullptr, nullptr, 0, nullptr, nullptr, &pool);
+                       counts_host, seq, nullptr, reinterpret_cast<hipStream_t>(stream_), nullptr, nullptr, flags, nullptr, nullptr, &pool);
 }
 
 int sttm_quadtree_merge_batch(int n_videos, const void* const* x, int64_t stride_t, int64_t stride_c, int64_t stride_h, int64_t stride_w,
@@ -745,7 +771,7 @@ int sttm_quadtree_merge_batch(int n_videos, const void* const* x, int64_t stride
                              feat_out + v0, npatch_out + v0, tlbr_out + v0, counts + (size_t)v0 * STTM_CNT_SLOTS,
                              counts_host ? counts_host + (size_t)v0 * STTM_CNT_SLOTS : nullptr, seq + v0,
                              nullptr, pool->s[lane], early_host ? early_host + (size_t)v0 * STTM_EARLY_SLOTS : nullptr,
-                             early_host ? n_early_out : nullptr, flags);
+                             early_host ? n_early_out : nullptr, flags, nullptr, nullptr, nullptr, S);
         }
         // join even after a failed launch: whatever was enqueued on the internal streams stays ordered before the caller's next work
         for (int i = 0; i < S; ++i) {

@@ -70,16 +70,17 @@ __device__ __forceinline__ unsigned long long pack_score(float v, int j) {
 // STRICTLY above the running one: for tiles that lie inside [0, nb) that is a compare and two selects per score, no branch.
 // Only the last, partial tile takes the general form (round 2's, which cost ~30 instructions and an exec-mask branch per score).
 typedef float tome_f32x16 __attribute__((ext_vector_type(16)));
-template <int QI, typename RoundFn>
-__device__ __forceinline__ void tome_running_max(const tome_f32x16 (&acc)[2][QI], float (&bestv)[QI], int (&bestj)[QI], int jlane, int nb,
+template <int QI, typename RoundFn, int PJ = 2>
+__device__ __forceinline__ void tome_running_max(const tome_f32x16 (&acc)[PJ][QI], float (&bestv)[QI], int (&bestj)[QI], int jlane, int nb,
                                                  bool inside, RoundFn rnd) {
+    static_assert(PJ != 4, "the four-wave kernel has its own running max (tome_running_max_agpr)");
     if (inside) {
 #pragma unroll
         for (int q = 0; q < QI; ++q) {
             float bv = bestv[q];
             int bc = -1;
 #pragma unroll
-            for (int p = 0; p < 2; ++p)
+            for (int p = 0; p < PJ; ++p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const float v = rnd(acc[p][q][e]);
@@ -87,6 +88,7 @@ __device__ __forceinline__ void tome_running_max(const tome_f32x16 (&acc)[2][QI]
                     bc = gt ? p * 32 + (e & 3) + 8 * (e >> 2) : bc;
                     bv = gt ? v : bv;
                 }
+            }
             bestj[q] = bc >= 0 ? jlane + bc : bestj[q];
             bestv[q] = bv;
         }
@@ -94,7 +96,7 @@ __device__ __forceinline__ void tome_running_max(const tome_f32x16 (&acc)[2][QI]
 #pragma unroll
         for (int q = 0; q < QI; ++q)
 #pragma unroll
-            for (int p = 0; p < 2; ++p)
+            for (int p = 0; p < PJ; ++p)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int j = jlane + p * 32 + (e & 3) + 8 * (e >> 2);
@@ -102,6 +104,46 @@ __device__ __forceinline__ void tome_running_max(const tome_f32x16 (&acc)[2][QI]
                     if (j < nb && (v > bestv[q] || (v == bestv[q] && j < bestj[q]))) { bestv[q] = v; bestj[q] = j; }
                 }
     }
+}
+
+template <typename T, int B> struct TomeAcc;
+template <int N, typename F> __device__ __forceinline__ void tome_static_for(F&& f);
+// The four-wave kernel's running max: block (p, q) of the AGPR accumulators is copied to 16 VGPRs and swept, one block at a time.
+// Branch-free also in a partial tile -- a candidate past nb scores -inf, which is never STRICTLY above the running maximum --, the
+// inside / partial decision a scalar branch per 32-candidate block.
+template <typename T, int QI, int PJ, typename RoundFn>
+__device__ __forceinline__ void tome_running_max_agpr(float (&bestv)[QI], int (&bestj)[QI], int jlane, int jwave, int nb, RoundFn rnd) {
+    tome_static_for<QI>([&](auto Q) {
+        constexpr int q = decltype(Q)::value;
+        float bv = bestv[q];
+        int bc = -1;
+        tome_static_for<PJ>([&](auto P) {
+            constexpr int p = decltype(P)::value;
+            float o[16];
+            TomeAcc<T, p * QI + q>::read(o);
+            if (jwave + p * 32 + 32 <= nb) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float v = rnd(o[e]);
+                    const bool gt = v > bv;
+                    bc = gt ? p * 32 + (e & 3) + 8 * (e >> 2) : bc;
+                    bv = gt ? v : bv;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int off = p * 32 + (e & 3) + 8 * (e >> 2);
+                    float v = rnd(o[e]);
+                    v = jlane + off < nb ? v : -INFINITY;
+                    const bool gt = v > bv;
+                    bc = gt ? off : bc;
+                    bv = gt ? v : bv;
+                }
+            }
+        });
+        bestj[q] = bc >= 0 ? jlane + bc : bestj[q];
+        bestv[q] = bv;
+    });
 }
 
 // Workgroups are dispatched round-robin over the 8 XCDs (blockIdx % 8), each with its own L2.  Logical ids are handed out so
@@ -297,6 +339,48 @@ template <> struct TomeMfma<f16_t> {
     typedef tome_f16x8 vec;
     static __device__ __forceinline__ f32x16_t run(vec a, vec b, f32x16_t c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
+
+// The four-wave kernel's accumulators (round 6): 16 blocks of 16 registers = the WHOLE AGPR file, named literally in inline assembly.
+// hipcc never sees them as values -- with the accumulators as C++ variables (through the MFMA builtin, or tied to the "a" register class)
+// it keeps part of them in VGPRs, copies all 256 to VGPRs in front of the running max, spills 0.3-1.1 KB per lane and evicts accumulator
+// blocks to scratch inside the MFMA sequence.  Every statement lists all AGPRs as clobbers (which also makes the kernel descriptor
+// allocate them), and tome.hip is compiled with -amdgpu-spill-vgpr-to-agpr=0, so the compiler holds nothing in an AGPR across them
+// (tests/test_kernel_resources.py audits the code object: no v_accvgpr_* outside these statements, no scratch).
+// hipcc does not see inside the strings: `s_nop 1` covers a compiler VALU write of an operand right in front of an MFMA; a chain of MFMAs
+// on one accumulator needs no wait states; tome_mfma_drain() precedes the first v_accvgpr_read after the last MFMA (8-pass XDL: 12+ states).
+#define TOME_AGPR_ALL "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
+template <typename T> struct TomeMfmaName;
+template <> struct TomeMfmaName<bf16_t> { typedef tome_bf16x8 vec; };
+template <> struct TomeMfmaName<f16_t> { typedef tome_f16x8 vec; };
+template <typename T, int B> struct TomeAcc {          // accumulator block B = a[16 B : 16 B + 15]
+    typedef typename TomeMfmaName<T>::vec vec;
+    static __device__ __forceinline__ void mfma(vec a, vec b) {
+        if constexpr (std::is_same<T, bf16_t>::value)
+            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(a), "v"(b), "i"(16 * B), "i"(16 * B + 15) : TOME_AGPR_ALL);
+        else
+            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(a), "v"(b), "i"(16 * B), "i"(16 * B + 15) : TOME_AGPR_ALL);
+    }
+    static __device__ __forceinline__ void zero(vec z) {      // D = 0 * 0 + 0
+        if constexpr (std::is_same<T, bf16_t>::value)
+            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[%c1:%c2], %0, %0, 0" :: "v"(z), "i"(16 * B), "i"(16 * B + 15) : TOME_AGPR_ALL);
+        else
+            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 a[%c1:%c2], %0, %0, 0" :: "v"(z), "i"(16 * B), "i"(16 * B + 15) : TOME_AGPR_ALL);
+    }
+    static __device__ __forceinline__ void read(float (&o)[16]) {
+        asm volatile("v_accvgpr_read_b32 %0, a%c8\n\tv_accvgpr_read_b32 %1, a%c9\n\tv_accvgpr_read_b32 %2, a%c10\n\tv_accvgpr_read_b32 %3, a%c11\n\t"
+                     "v_accvgpr_read_b32 %4, a%c12\n\tv_accvgpr_read_b32 %5, a%c13\n\tv_accvgpr_read_b32 %6, a%c14\n\tv_accvgpr_read_b32 %7, a%c15"
+                     : "=v"(o[0]), "=v"(o[1]), "=v"(o[2]), "=v"(o[3]), "=v"(o[4]), "=v"(o[5]), "=v"(o[6]), "=v"(o[7])
+                     : "i"(16 * B), "i"(16 * B + 1), "i"(16 * B + 2), "i"(16 * B + 3), "i"(16 * B + 4), "i"(16 * B + 5), "i"(16 * B + 6), "i"(16 * B + 7));
+        asm volatile("v_accvgpr_read_b32 %0, a%c8\n\tv_accvgpr_read_b32 %1, a%c9\n\tv_accvgpr_read_b32 %2, a%c10\n\tv_accvgpr_read_b32 %3, a%c11\n\t"
+                     "v_accvgpr_read_b32 %4, a%c12\n\tv_accvgpr_read_b32 %5, a%c13\n\tv_accvgpr_read_b32 %6, a%c14\n\tv_accvgpr_read_b32 %7, a%c15"
+                     : "=v"(o[8]), "=v"(o[9]), "=v"(o[10]), "=v"(o[11]), "=v"(o[12]), "=v"(o[13]), "=v"(o[14]), "=v"(o[15])
+                     : "i"(16 * B + 8), "i"(16 * B + 9), "i"(16 * B + 10), "i"(16 * B + 11), "i"(16 * B + 12), "i"(16 * B + 13), "i"(16 * B + 14), "i"(16 * B + 15));
+    }
+};
+__device__ __forceinline__ void tome_mfma_drain() { asm volatile("s_nop 15\n\ts_nop 3" ::: "memory"); }
+template <int N, typename F> __device__ __forceinline__ void tome_static_for(F&& f) {
+    if constexpr (N > 0) { tome_static_for<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
+}
 
 // Same structure as k_tome_match (transposed tile D[j][i] = b_j . a_i, lane = one a-row, running max in registers, packed
 // atomicMax), on 16-bit operands: LDS tiles are [row][k] (what the 32x32x16 operand wants: 8 consecutive k per lane, one
@@ -571,8 +655,11 @@ constexpr int TG_BUF = 65536;                   // bytes of one stage: [matrix A
 // ABL (dev builds, STTM_TOME_ABL): 1 = no DMA after the prologue (MFMA side alone), 2 = no MFMAs (DMA + barriers + fragment reads alone),
 // 5 = MFMAs alone (no fragment reads, barriers or DMA in the loop), 6 = MFMAs + fragment reads (no barriers, no DMA): outputs invalid
 // in all four; 3 = the round-2 form (general running max everywhere, reads in front), 4 = reads after the FIRST MFMA.
-template <int NP, int TERMS, typename T, int ABL = 0>
-__global__ void __launch_bounds__(512, 2) k_tome_match_glds(const uint16_t* __restrict__ ap, const uint16_t* __restrict__ bp,
+// PJ = 32-row b-subtiles per wave (round 6): 2 = eight waves of 64 (j) x 128 (i), two per SIMD; 4 = FOUR waves of 128 x 128, one per SIMD with
+// the whole 512-register budget -- its 256 accumulators in the AGPR half, 16 MFMAs per k16 step and plane product between two fragment waits,
+// a quarter fewer LDS fragment bytes per MFMA, no second wave contending for the SIMD's issue slots.
+template <int NP, int TERMS, typename T, int ABL = 0, int PJ = 2>
+__global__ void __launch_bounds__(128 * (8 / PJ), PJ == 4 ? 1 : 2) k_tome_match_glds(const uint16_t* __restrict__ ap, const uint16_t* __restrict__ bp,
                                                              int na, int nb, int D, int jsplit,
                                                              unsigned long long* __restrict__ best /*[na]*/) {
     static_assert((NP == 2 && (TERMS == 3 || TERMS == 4)) || (NP == 1 && TERMS == 1), "plane / term combination");
@@ -589,6 +676,8 @@ __global__ void __launch_bounds__(512, 2) k_tome_match_glds(const uint16_t* __re
     constexpr int R256 = 256 / RB;               // rows per 256 bytes of LDS (the bank period)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NWAVE = 2 * (8 / PJ);          // 2 along i x (4 or 2) along j
+    constexpr int NPIECE = 64 / NWAVE;           // 1 KB DMA pieces per wave and stage
     const int wi = wave & 1, wj = wave >> 1;
     const int lid = tome_xcd_logical_id();
     // A workgroup owns a contiguous range [p_lo, p_hi) of tile products in row-major order (p = itile * jtiles + jtile).
@@ -613,28 +702,34 @@ __global__ void __launch_bounds__(512, 2) k_tome_match_glds(const uint16_t* __re
     if (S <= 0) return;
 
     const int prow = lane / CPR;
-    auto piece_row = [&](int g) { return (g % PPM) * RPP + prow; };
-    auto src_chunk = [&](int g) { return (lane % CPR) ^ ((piece_row(g) / R256) & (CPR - 1)); };
-    // piece c of stage st (product p_lo + st / NK, k0 = (st % NK) * KS) into buffer st & 1
-    auto issue_piece = [&](int c, int st) {
-        if ((ABL == 1 || ABL == 5 || ABL == 6) && st > 1) return;
-        const int g = wave + 8 * c, buf = st & 1;
-        const int prod = p_lo + st / NK, it = prod / jtiles;
-        const int j0 = (prod - it * jtiles) * TG_T, k0 = (st % NK) * KS;
-        if (c < 4) {
-            // (the address is rebuilt per piece, like b's: four pointers kept per lane cost the two-plane kernel its last registers)
-            const int plane = (g / PPM) % NP;
-            const char* src = reinterpret_cast<const char*>(ap + ((int64_t)plane * na + min(it * TG_T + piece_row(g), na - 1)) * D + k0 + src_chunk(g) * 8);
-            __builtin_amdgcn_global_load_lds((tome_gptr)src, (tome_lptr)(tg_smem + buf * TG_BUF + g * 1024), 16, 0, 0);
-        } else {
-            const int plane = (g / PPM) % NP;
-            const char* src = reinterpret_cast<const char*>(bp + ((int64_t)plane * nb + min(j0 + piece_row(g), nb - 1)) * D + k0 + src_chunk(g) * 8);
-            __builtin_amdgcn_global_load_lds((tome_gptr)src, (tome_lptr)(tg_smem + buf * TG_BUF + g * 1024), 16, 0, 0);
-        }
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(ap), 0, NP * na * D * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(bp), 0, NP * nb * D * 2, 0x00020000);
+    const uint32_t dma_voff = (uint32_t)((prow * D + ((lane % CPR) ^ ((4 * wave + prow / R256) & (CPR - 1))) * 8) * 2);
+    // Round 6: buffer-addressed DMA with a RUNNING stage state.  The piece's first row and k0 are a SCALAR byte offset, every lane
+    // adds ONE offset that is the same for all of the wave's pieces (the source-chunk swizzle depends on the piece only through its parity,
+    // which is the wave's), rows past the matrix are cut off by the descriptor's range check (they read zeros, or -- first plane of two --
+    // the other plane's rows: scores of rows >= na are never published, candidates >= nb never compared).  No 64-bit per-lane address
+    // arithmetic and no per-piece VGPRs; the (a-tile, j-tile, k-stage) of a stage is carried from stage to stage instead of being divided
+    // out of the stage number per piece (st / NK, prod / jtiles with run-time divisors: ~45 scalar instructions a piece, 700 a stage --
+    // with one wave per SIMD nothing else issues meanwhile).
+    struct Feed { int it, jt, k; };
+    auto feed_next = [&](Feed& f) {
+        if (++f.k == NK) { f.k = 0; if (++f.jt == jtiles) { f.jt = 0; ++f.it; } }
+    };
+    auto issue_piece4 = [&](int c, const Feed& f, int buf, bool prologue = false) {
+        if ((ABL == 1 || ABL == 5 || ABL == 6) && !prologue) return;
+        constexpr int HALF = NPIECE / 2;
+        const int cc = c % HALF;
+        const bool is_a = c < HALF;
+        const int g = wave + NWAVE * cc + (is_a ? 0 : 32);
+        const int plane = ((NWAVE * cc) / PPM) % NP, rr = (NWAVE * cc) % PPM;          // (wave < NWAVE <= PPM: the wave does not change them)
+        const int row0 = plane * (is_a ? na : nb) + (is_a ? f.it : f.jt) * TG_T + (wave + rr) * RPP;
+        const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane((row0 * D + f.k * KS) * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(is_a ? rs_a : rs_b, (tome_lptr)(tg_smem + buf * TG_BUF + g * 1024), 16, dma_voff, soff, 0, 0);
     };
     const int sw = (lcol / R256) & (CPR - 1);
-    const int a_off = (wi * 128 + lcol) * RB, b_off = NP * PLANE + (wj * 64 + lcol) * RB;
-    struct Frag { vec b[2][NP], a[QI][NP]; };
+    const int a_off = (wi * 128 + lcol) * RB, b_off = NP * PLANE + (wj * 32 * PJ + lcol) * RB;
+    struct Frag { vec b[PJ][NP], a[QI][NP]; };
     auto read_frag = [&](Frag& f, int st, int step) {
         if (ABL == 5 && st + step > 0) return;                 // MFMAs alone: the first fragments for ever
         const char* base = tg_smem + (st & 1) * TG_BUF;
@@ -643,7 +738,7 @@ __global__ void __launch_bounds__(512, 2) k_tome_match_glds(const uint16_t* __re
         for (int pi = 0; pi < NP; ++pi) {
             const int pl = NP - 1 - pi;         // the l planes first: the first products need them
 #pragma unroll
-            for (int p = 0; p < 2; ++p) f.b[p][pl] = *reinterpret_cast<const vec*>(base + b_off + pl * PLANE + p * 32 * RB + coff);
+            for (int p = 0; p < PJ; ++p) f.b[p][pl] = *reinterpret_cast<const vec*>(base + b_off + pl * PLANE + p * 32 * RB + coff);
 #pragma unroll
             for (int q = 0; q < QI; ++q) f.a[q][pl] = *reinterpret_cast<const vec*>(base + a_off + pl * PLANE + q * 32 * RB + coff);
         }
@@ -653,21 +748,39 @@ __global__ void __launch_bounds__(512, 2) k_tome_match_glds(const uint16_t* __re
     int bestj[QI];
 #pragma unroll
     for (int q = 0; q < QI; ++q) { bestv[q] = -INFINITY; bestj[q] = 0x7fffffff; }
-    f32x16_t acc[2][QI];
+    // PJ == 2: accumulators as values (hipcc's registers).  PJ == 4: the literal AGPR blocks of TomeAcc, cleared by an MFMA of zero operands
+    // with C = 0 (16 of the 1024+ MFMAs of a tile product; taking C = 0 in the product's first MFMA needs a branch between two asm forms
+    // in the k-loop).
+    constexpr int NACC = PJ == 4 ? 1 : PJ;
+    f32x16_t acc[NACC][QI];
+    auto clear_acc = [&]() {
+        if constexpr (PJ == 4) {
+            vec z;
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
+            for (int e = 0; e < 8; ++e) z[e] = 0;
+            tome_static_for<PJ * QI>([&](auto B) { TomeAcc<T, decltype(B)::value>::zero(z); });
+        } else {
 #pragma unroll
-        for (int q = 0; q < QI; ++q)
+            for (int p = 0; p < PJ; ++p)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[p][q][e] = 0.f;
+                for (int q = 0; q < QI; ++q)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[p][q][e] = 0.f;
+        }
+    };
+    clear_acc();
 
     // prologue: stages 0 and 1 in flight, stage 0 landed, its first fragments read
+    Feed f1 = {p_lo / jtiles, p_lo % jtiles, 0}, f2 = f1;          // the stages st + 1 and st + 2 of the loop below
 #pragma unroll
-    for (int c = 0; c < 8; ++c) issue_piece(c, 0);
+    for (int c = 0; c < NPIECE; ++c) issue_piece4(c, f1, 0, true);
+    feed_next(f1);
     if (S > 1) {
 #pragma unroll
-        for (int c = 0; c < 8; ++c) issue_piece(c, 1);
+        for (int c = 0; c < NPIECE; ++c) issue_piece4(c, f1, 1, true);
     }
+    f2 = f1;
+    feed_next(f2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     Frag fr[2];
@@ -681,7 +794,9 @@ __global__ void __launch_bounds__(512, 2) k_tome_match_glds(const uint16_t* __re
             Frag& nxt = fr[(step + 1) & 1];
             const bool last = step == NSTEP - 1;
             __builtin_amdgcn_sched_barrier(0);      // the MFMAs of the step before stay in front of this step's barrier / reads
-            constexpr int late_n = (NP == 1 && ABL != 3) ? (ABL == 4 ? 1 : QI) : 0;   // MFMAs in front of the next step's fragment reads
+            // (PJ == 4: hipcc counts the fragment waits in front of the asm MFMAs one by one -- lgkmcnt(11) .. (8) with the next step's eight
+            // reads already behind them --, so the reads can go first and get the whole step's 16 MFMAs to land)
+            constexpr int late_n = (NP == 1 && ABL != 3 && PJ != 4) ? (ABL == 4 ? 1 : QI) : 0;   // MFMAs in front of the next step's fragment reads
             constexpr bool late = late_n > 0;
             if (!last) {
                 if (!late) read_frag(nxt, st, step + 1);
@@ -700,8 +815,32 @@ __global__ void __launch_bounds__(512, 2) k_tome_match_glds(const uint16_t* __re
             for (int term = 4 - TERMS; term < 4; ++term) {
                 // l.l, l.h, h.l, h.h (small terms first); one plane: the only term is h.h
                 const int pb = NP == 2 && (term == 0 || term == 1), pa = NP == 2 && (term == 0 || term == 2);
+                if constexpr (PJ == 4) {
+                    tome_static_for<PJ * QI>([&](auto B) {
+                        constexpr int b = decltype(B)::value, p = b / QI, q = b % QI;
+                        TomeAcc<T, b>::mfma(cur.b[p][pb], cur.a[q][pa]);
+                        // One wave per SIMD: nobody else covers a burst of DMA issues (~60 cycles each against an MFMA's 32), so the pieces
+                        // go out one at a time behind MFMAs.  The buffer of stage st is free from the barrier in front of its last step
+                        // until the first reads of stage st+2, one stage later: the pieces of stage st+2 are spread over the first
+                        // NSTEP-1 steps of that window -- this stage's last step and the next stage's steps 0 .. NSTEP-3 --, the window's
+                        // last step is left for the last piece to land.
+                        {
+                            constexpr int WSTEPS = NSTEP > 2 ? 2 : 1;                         // window steps that issue
+                            constexpr int EVERY = WSTEPS * PJ * QI * TERMS / NPIECE;          // MFMAs per piece (3)
+                            const int wpos = last ? 0 : step + 1;
+                            const int tgt = last ? st + 2 : st + 1;
+                            const int m = (wpos * TERMS + term - (4 - TERMS)) * PJ * QI + b;  // MFMA number inside the window (a constant once unrolled)
+                            if (wpos < WSTEPS && tgt >= 2 && tgt < S && m % EVERY == 0 && m / EVERY < NPIECE) issue_piece4(m / EVERY, last ? f2 : f1, tgt & 1);
+                        }
+                        if (late_n == QI && !last && term == 4 - TERMS && b == QI - 1) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            read_frag(nxt, st, step + 1);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    });
+                } else
 #pragma unroll
-                for (int p = 0; p < 2; ++p) {
+                for (int p = 0; p < PJ; ++p) {
 #pragma unroll
                     for (int q = 0; q < QI; ++q) {
                         if (ABL != 2) acc[p][q] = TomeMfma<T>::run(cur.b[p][pb], cur.a[q][pa], acc[p][q]);
@@ -718,28 +857,30 @@ __global__ void __launch_bounds__(512, 2) k_tome_match_glds(const uint16_t* __re
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                if (last) {
+                if (last && PJ != 4) {
                     const int gi = term - (4 - TERMS);
                     if (feed) {
 #pragma unroll
-                        for (int c = 0; c < 8; ++c)
-                            if (c * TERMS / 8 == gi) issue_piece(c, st + 2);
+                        for (int c = 0; c < NPIECE; ++c)
+                            if (c * TERMS / NPIECE == gi) issue_piece4(c, f2, st & 1);
                     }
                 }
             }
         }
+        f1 = f2;
+        feed_next(f2);
         if ((st + 1) % NK == 0) {
             // end of a tile product: running max (split: on the scaled scores, the factor 2^-24 is applied once at the end)
             const int prod = p_lo + st / NK, it = prod / jtiles, jt = prod - it * jtiles;
             const int j0 = jt * TG_T;
-            tome_running_max<QI>(acc, bestv, bestj, j0 + wj * 64 + 4 * lhalf, nb, ABL != 3 && j0 + TG_T <= nb,
-                                 [](float v) { return NP == 1 ? tome_round<T>(v) : v; });
-#pragma unroll
-            for (int p = 0; p < 2; ++p)
-#pragma unroll
-                for (int q = 0; q < QI; ++q)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[p][q][e] = 0.f;
+            auto rnd_fn = [](float v) { return NP == 1 ? tome_round<T>(v) : v; };
+            if constexpr (PJ == 4) {
+                tome_mfma_drain();
+                if (ABL != 7) tome_running_max_agpr<T, QI, PJ>(bestv, bestj, j0 + wj * 32 * PJ + 4 * lhalf, j0 + wj * 32 * PJ, nb, rnd_fn);
+            } else {
+                tome_running_max<QI, decltype(rnd_fn), NACC>(acc, bestv, bestj, j0 + wj * 32 * PJ + 4 * lhalf, nb, ABL != 3 && j0 + TG_T <= nb, rnd_fn);
+            }
+            clear_acc();
             if (st + 1 == S || jt + 1 == jtiles) {
                 // last product of this a-tile in the range: publish its rows, start over for the next a-tile
 #pragma unroll
@@ -1264,8 +1405,9 @@ int sttm_tome_step(const void* x_, const float* size, const int64_t* idx, int n,
                                n_head, p.D, p.Dp, ap, p.na, bp, p.nb);
         // tome_split: 1 = four product terms, 2 = three (without l.l); 3/4 force the 128-tile / the 256-tile DMA kernel (4 terms),
         // 5/6 the same with 3 terms.  The 256-tile kernel wins from ~6 k tokens on (measured cross-over: T = 32 frames of 196).
-        const int terms = (split == 2 || split == 5 || split == 6) ? 3 : 4;
-        const bool big = split == 4 || split == 6 || ((split == 1 || split == 2) && p.na >= 3072);
+        // 7 = the four-wave form of the 256-tile kernel (128 x 128 wave tiles, round 6), 3 terms
+        const int terms = (split == 2 || split == 5 || split == 6 || split == 7) ? 3 : 4;
+        const bool big = split == 4 || split == 6 || split == 7 || ((split == 1 || split == 2) && p.na >= 3072);
         if (big) {
             int it = (p.na + TG_T - 1) / TG_T;
             int js = pick_jsplit(it, TG_T, 1);
@@ -1280,7 +1422,8 @@ int sttm_tome_step(const void* x_, const float* size, const int64_t* idx, int n,
             else if (abl == 6) hipLaunchKernelGGL((k_tome_match_glds<2, 4, f16_t, 6>), dim3(js ? it * js : it), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
             else
 #endif
-            if (terms == 4) hipLaunchKernelGGL((k_tome_match_glds<2, 4, f16_t>), dim3(js ? it * js : it), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
+            if (split == 7) hipLaunchKernelGGL((k_tome_match_glds<2, 3, f16_t, 0, 4>), dim3(js ? it * js : it), dim3(256), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
+            else if (terms == 4) hipLaunchKernelGGL((k_tome_match_glds<2, 4, f16_t>), dim3(js ? it * js : it), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
             else hipLaunchKernelGGL((k_tome_match_glds<2, 3, f16_t>), dim3(js ? it * js : it), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
         } else {
             const size_t lds = (size_t)(2 * TM_I + 2 * TM_J) * (TM_K + 8) * 2;
@@ -1295,15 +1438,15 @@ int sttm_tome_step(const void* x_, const float* size, const int64_t* idx, int n,
         // 256-tile one), like the split path
         uint16_t* ap = reinterpret_cast<uint16_t*>(ahat);
         uint16_t* bp = reinterpret_cast<uint16_t*>(bhat);
-        const bool big = split == 4 || split == 6 || (split != 3 && split != 5 && p.na >= 3072);
+        const bool big = split == 4 || split == 6 || split == 7 || (split != 3 && split != 5 && p.na >= 3072);
         int it = (p.na + TG_T - 1) / TG_T;
         int js = pick_jsplit(it, TG_T, 1);
         pick_flat(it, js);
 #ifdef STTM_DEV
         const int abl16 = getenv("STTM_TOME_ABL") ? atoi(getenv("STTM_TOME_ABL")) : 0;
-        constexpr int ABL16A = 3, ABL16B = 4, ABL16C = 5;
+        constexpr int ABL16A = 3, ABL16B = 4, ABL16C = 5, ABL4A = 1, ABL4B = 5, ABL4C = 6, ABL4D = 7;      // (four-wave form: 1 no DMA, 5 MFMAs alone, 6 + fragment reads, 7 no running max)
 #else
-        constexpr int abl16 = 0, ABL16A = 0, ABL16B = 0, ABL16C = 0;
+        constexpr int abl16 = 0, ABL16A = 0, ABL16B = 0, ABL16C = 0, ABL4A = 0, ABL4B = 0, ABL4C = 0, ABL4D = 0;
 #endif
 #define STTM_TOME_16(TT)                                                                                                            \
         do {                                                                                                                        \
@@ -1314,6 +1457,11 @@ int sttm_tome_step(const void* x_, const float* size, const int64_t* idx, int n,
             if (big && abl16 == 3) hipLaunchKernelGGL((k_tome_match_glds<1, 1, TT, ABL16A>), dim3(js ? it * js : it), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best); \
             else if (big && abl16 == 4) hipLaunchKernelGGL((k_tome_match_glds<1, 1, TT, ABL16B>), dim3(js ? it * js : it), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best); \
             else if (big && abl16 == 5) hipLaunchKernelGGL((k_tome_match_glds<1, 1, TT, ABL16C>), dim3(js ? it * js : it), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best); \
+            else if (big && split == 7 && abl16 == 1) hipLaunchKernelGGL((k_tome_match_glds<1, 1, TT, ABL4A, 4>), dim3(js ? it * js : it), dim3(256), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best); \
+            else if (big && split == 7 && abl16 == 5) hipLaunchKernelGGL((k_tome_match_glds<1, 1, TT, ABL4B, 4>), dim3(js ? it * js : it), dim3(256), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best); \
+            else if (big && split == 7 && abl16 == 6) hipLaunchKernelGGL((k_tome_match_glds<1, 1, TT, ABL4C, 4>), dim3(js ? it * js : it), dim3(256), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best); \
+            else if (big && split == 7 && abl16 == 7) hipLaunchKernelGGL((k_tome_match_glds<1, 1, TT, ABL4D, 4>), dim3(js ? it * js : it), dim3(256), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best); \
+            else if (big && split == 7) hipLaunchKernelGGL((k_tome_match_glds<1, 1, TT, 0, 4>), dim3(js ? it * js : it), dim3(256), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best); \
             else if (big) hipLaunchKernelGGL((k_tome_match_glds<1, 1, TT>), dim3(js ? it * js : it), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best); \
             else hipLaunchKernelGGL(k_tome_match16<TT>, dim3(itiles * jsplit), dim3(256), 0, stream, ap, bp, p.na, p.nb, p.Dp, jsplit, best); \
         } while (0)

@@ -421,15 +421,22 @@ def _apply_side_tensor(v, ctx, root_level, sum_mode):
 
 
 def get_quadtree_features_batch(videos, threshold, temporal_thresh=-1.0, root_level=0, weighted_avg=False,
-                                slow_ver=False, head_dim=None, events=None):
+                                slow_ver=False, head_dim=None, events=None, out=None):
     """Extension (not in the reference, whose API is one video per call): merge a LIST of videos and return the list of
     (features, num_patches, tlbr) triples -- results identical to calling get_quadtree_features on each.
 
-    Videos of one shape / dtype / stride set go through sttm_quadtree_merge_batch together: every kernel gets a second grid
-    dimension over the videos, so the launch ramps and tails and the latency-bound label stage of one video overlap the
-    bandwidth-bound kernels of its neighbours -- on the caller's own stream, with no side streams.  The host waits for the
-    per-video token counts only after everything has been enqueued.  Same per-stream state (lock, scratch, landing pads) as
-    the one-video call."""
+    Videos of one shape / dtype / stride set go through sttm_quadtree_merge_batch together.  Default (stage-skewed form, round 5): the
+    library deals them out to `batch_streams` INTERNAL streams (3; created on first use per host thread and device, released by
+    `release_streams()`) in launch sets of `batch_sub` videos (8), forked from and joined back into the current stream, so that
+    consecutive launch sets sit in different stages at any moment -- the latency-bound label stage and the launch ramps of one set run
+    under the bandwidth-bound kernels of the others.  `_lib.configure(batch_streams=0)` selects the lockstep form (every kernel once per
+    group of videos, on the caller's stream only).  The host waits for the per-video token counts only after everything has been
+    enqueued.  Same per-stream state (lock, scratch, landing pads) as the one-video call.
+
+    Memory: N' is known only after the kernels ran, so every video gets worst-case output rows ([T*H*W, C] ...); without `out` a call
+    allocates them (96 headline videos: 10 GB for 4.4 GB of results, alive as long as the returned views).  `out = (features [n, T*H*W, C],
+    num_patches [n, T*H*W] int32, tlbr [n, T*H*W, 5] int32)` -- CALLER-OWNED blocks for n >= len(videos) videos of ONE shape / dtype,
+    reused call after call -- makes the call allocation-free; the results are leading views into them."""
     if not videos:
         return []
     dev = videos[0].device
@@ -440,12 +447,17 @@ def get_quadtree_features_batch(videos, threshold, temporal_thresh=-1.0, root_le
         st = _acquire_state(dev)
         try:
             return _with_barrier_retry(st, lambda flags: _batch_locked(st, videos, dev, threshold, temporal_thresh, root_level,
-                                                                        weighted_avg, slow_ver, head_dim, events, flags))
+                                                                        weighted_avg, slow_ver, head_dim, events, flags, out))
         finally:
             st.lock.release()
 
 
-def _batch_locked(st, videos, dev, threshold, temporal_thresh, root_level, weighted_avg, slow_ver, head_dim, events, flags):
+def release_streams():
+    """Destroy the internal streams / events the batch entry point created for the calling host thread (C ABI: sttm_release_streams)."""
+    return _lib.load().sttm_release_streams()
+
+
+def _batch_locked(st, videos, dev, threshold, temporal_thresh, root_level, weighted_avg, slow_ver, head_dim, events, flags, dest=None):
     lib = _lib.load()
     head = 0 if head_dim is None else int(head_dim)
     out = [None] * len(videos)
@@ -476,9 +488,21 @@ def _batch_locked(st, videos, dev, threshold, temporal_thresh, root_level, weigh
         n = len(ids)
         # the outputs of a group in THREE allocations (worst-case rows per video, returned as leading views like the one-video call):
         # one torch.empty per tensor and video kept the host busy for ~7 us per video between two calls, with the device idle
-        feats = torch.empty((n, N, C), dtype=dt, device=dev)
-        npatches = torch.empty((n, N), dtype=torch.int32, device=dev)
-        tlbrs = torch.empty((n, N, 5), dtype=torch.int32, device=dev)
+        if dest is not None:
+            if len(groups) != 1:
+                raise ValueError("out= takes videos of ONE shape / dtype / stride set")
+            feats, npatches, tlbrs = dest
+            ok = (feats.is_cuda and feats.device == dev and feats.dtype == dt and feats.is_contiguous() and tuple(feats.shape[1:]) == (N, C)
+                  and feats.shape[0] >= n and npatches.dtype == torch.int32 and npatches.is_contiguous() and tuple(npatches.shape) == (feats.shape[0], N)
+                  and npatches.device == dev and tlbrs.dtype == torch.int32 and tlbrs.is_contiguous() and tlbrs.device == dev
+                  and tuple(tlbrs.shape) == (feats.shape[0], N, 5))
+            if not ok:
+                raise ValueError(f"out= must be contiguous (features [n, {N}, {C}] {dt}, num_patches [n, {N}] int32, tlbr [n, {N}, 5] int32) on "
+                                 f"{dev} with n >= {n}")
+        else:
+            feats = torch.empty((n, N, C), dtype=dt, device=dev)
+            npatches = torch.empty((n, N), dtype=torch.int32, device=dev)
+            tlbrs = torch.empty((n, N, 5), dtype=torch.int32, device=dev)
         eb = feats.element_size()
         f0, p0, t0 = feats.data_ptr(), npatches.data_ptr(), tlbrs.data_ptr()
         vp = ctypes.c_void_p * n
@@ -511,7 +535,7 @@ def _batch_locked(st, videos, dev, threshold, temporal_thresh, root_level, weigh
             cnt = [0] * _lib.CNT_SLOTS
             cnt[_lib.CNT_OUT], cnt[_lib.CNT_OVERFLOW] = n_out, ovf
             _check_overflow(ovf, cnt)
-        out[j] = _sized(feat, npatch, tlbr, n_out)
+        out[j] = _sized(feat, npatch, tlbr, n_out, owned=dest is None)
     return out
 
 
@@ -649,27 +673,32 @@ def get_quadtree_features_from_pooled_input(image_feature, threshold, temporal_t
                                      weighted_avg, False, slow_ver, head_dim)
     dev = x.device
     N = T * H * W
+    def run(flags):
+        nbytes = _workspace_bytes(lib, T, H, W, C, dtype, root_level)
+        st.reserve(dev, nbytes, 16)
+        st.key = None                                                   # (the argument block of the plain merge is not what ran last)
+        feat = torch.empty((N, C), dtype=x.dtype, device=dev)
+        npatch = torch.empty(N, dtype=torch.int32, device=dev)
+        tlbr = torch.empty((N, 5), dtype=torch.int32, device=dev)
+        seq = _next_seq()
+        rc = lib.sttm_quadtree_merge_pooled(x.data_ptr(), T, side_h, side_w, C, dtype, m, int(stride), float(threshold), float(temporal_thresh),
+                                            int(root_level), int(bool(weighted_avg)), int(bool(slow_ver)), st.ws.data_ptr(), st.ws.numel(),
+                                            feat.data_ptr(), npatch.data_ptr(), tlbr.data_ptr(), st.counts.data_ptr(), st.host_ptr, seq, st.handle,
+                                            flags)
+        _lib.raise_for(rc)
+        if lib.sttm_wait_counts(st.host_ptr, seq, _WAIT_TIMEOUT_US) != 0:
+            st.host_view.copy_(st.counts[0], non_blocking=True)        # fallback: classic D2H + stream sync
+            torch.cuda.current_stream(dev).synchronize()
+        cnt = st.host_view.tolist()
+        _check_overflow(cnt[_lib.CNT_OVERFLOW], cnt)                    # (a grid-barrier timeout: _with_barrier_retry repeats the call)
+        return feat, npatch, tlbr, cnt
+
     with torch.cuda.device(dev):
         st = _acquire_state(dev)
         try:
-            nbytes = _workspace_bytes(lib, T, H, W, C, dtype, root_level)
-            st.reserve(dev, nbytes, 16)
-            st.key = None                                                   # (the argument block of the plain merge is not what ran last)
-            feat = torch.empty((N, C), dtype=x.dtype, device=dev)
-            npatch = torch.empty(N, dtype=torch.int32, device=dev)
-            tlbr = torch.empty((N, 5), dtype=torch.int32, device=dev)
-            seq = _next_seq()
-            rc = lib.sttm_quadtree_merge_pooled(x.data_ptr(), T, side_h, side_w, C, dtype, m, int(stride), float(threshold), float(temporal_thresh),
-                                                int(root_level), int(bool(weighted_avg)), int(bool(slow_ver)), st.ws.data_ptr(), st.ws.numel(),
-                                                feat.data_ptr(), npatch.data_ptr(), tlbr.data_ptr(), st.counts.data_ptr(), st.host_ptr, seq, st.handle)
-            _lib.raise_for(rc)
-            if lib.sttm_wait_counts(st.host_ptr, seq, _WAIT_TIMEOUT_US) != 0:
-                st.host_view.copy_(st.counts[0], non_blocking=True)        # fallback: classic D2H + stream sync
-                torch.cuda.current_stream(dev).synchronize()
-            cnt = st.host_view.tolist()
+            feat, npatch, tlbr, cnt = _with_barrier_retry(st, run)
         finally:
             st.lock.release()
-    _check_overflow(cnt[_lib.CNT_OVERFLOW], cnt)
     return _sized(feat, npatch, tlbr, cnt[_lib.CNT_OUT])
 
 

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"libsttm_hip.so does not export {n}"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
-    assert lib.sttm_abi_version() == _lib.ABI_VERSION == 7
+    assert lib.sttm_abi_version() == _lib.ABI_VERSION == 8
 
 
 @pytest.mark.parametrize("H,W", [(14, 14), (27, 27), (20, 36), (18, 26), (13, 24), (16, 22), (10, 30), (7, 7),

@@ -565,6 +565,56 @@ def test_batched_extension_equals_per_video_calls():
             assert torch.equal(t, et) and torch.equal(n, en) and torch.equal(f, ef)
 
 
+def test_batch_into_caller_owned_blocks_and_stream_release():
+    """out=: the batch entry point writes into caller-owned worst-case blocks (no allocation per call; results are leading views into
+    them); release_streams() destroys the calling thread's internal streams, the next call creates them again."""
+    from sttm_amd import get_quadtree_features, get_quadtree_features_batch
+    from sttm_amd.quadtree_interface import release_streams
+    from sttm_amd.synth import synth_video
+    dev = _dev()
+    vids = [synth_video(12, 256, 14, 14, seed=120 + i).to(dev) for i in range(11)]
+    single = [get_quadtree_features(v, 0.85, 0.55, 1) for v in vids]
+    N = 12 * 196
+    blocks = (torch.empty((16, N, 256), device=dev), torch.empty((16, N), dtype=torch.int32, device=dev),
+              torch.empty((16, N, 5), dtype=torch.int32, device=dev))
+    for rep in range(2):
+        batch = get_quadtree_features_batch(vids, 0.85, 0.55, 1, out=blocks)
+        torch.cuda.synchronize()
+        for k, ((f, n, t), (ef, en, et)) in enumerate(zip(batch, single)):
+            assert torch.equal(t, et) and torch.equal(n, en) and torch.equal(f, ef)
+            assert f.data_ptr() == blocks[0][k].data_ptr() and t.data_ptr() == blocks[2][k].data_ptr()
+        assert release_streams() >= 0
+    assert release_streams() == 0            # nothing left to release
+    with pytest.raises(ValueError):
+        get_quadtree_features_batch(vids, 0.85, 0.55, 1, out=(blocks[0][:4], blocks[1][:4], blocks[2][:4]))
+    with pytest.raises(ValueError):
+        get_quadtree_features_batch(vids + [synth_video(6, 256, 14, 14, seed=1).to(dev)], 0.85, 0.55, 1, out=blocks)
+
+
+BATCH_PATHS = [dict(batch_streams=0), dict(batch_streams=2, batch_sub=3), dict(force_gmem_labels=1), dict(no_fuse=1), dict(col_walk=1),
+               dict(batch_streams=6, batch_sub=2)]
+
+
+@pytest.mark.parametrize("opts", BATCH_PATHS, ids=lambda o: "+".join(f"{k}={v}" for k, v in o.items()))
+def test_batch_entry_point_under_the_alternative_paths(opts):
+    """The batch entry point in its lockstep form, with other stream / launch-set counts, on the global-scratch and the two-launch label
+    paths and on the column-walk spatial stage: the same bits as one-video calls on the default path."""
+    from sttm_amd import _lib, get_quadtree_features, get_quadtree_features_batch
+    from sttm_amd.synth import synth_video
+    dev = _dev()
+    vids = [synth_video(T, 512, 14, 14, seed=140 + i).to(dev) for i, T in enumerate([20] * 19 + [7, 33])]
+    single = [get_quadtree_features(v, 0.80, 0.50, 1) for v in vids]
+    defaults = dict(batch_streams=3, batch_sub=8, force_gmem_labels=0, no_fuse=0, col_walk=0)
+    try:
+        _lib.configure(**opts)
+        batch = get_quadtree_features_batch(vids, 0.80, 0.50, 1)
+        torch.cuda.synchronize()
+    finally:
+        _lib.configure(**defaults)
+    for (f, n, t), (ef, en, et) in zip(batch, single):
+        assert torch.equal(t, et) and torch.equal(n, en) and torch.equal(f, ef)
+
+
 def test_nchw_contiguous_input_is_accepted():
     """Not the production layout: the wrapper makes one channels-last copy and results are unchanged."""
     from oracle import sttm_oracle as O
@@ -714,16 +764,22 @@ def test_tome_golden_vectors(path):
         assert torch.equal(idx.cpu(), c["idx"])          # r = n/2: output is exactly the odd tokens, in order
 
 
-def _compare_tome(f, i, ef, ei, tol, what):
+def _compare_tome(f, i, ef, ei, tol, what, max_ids=1, max_rows=2):
     """Kept token ids as sets; features as (token id -> feature) maps on the ids both sides kept.  A near-tie at the top-r
-    boundary of a LATER iteration may swap which of two a-tokens is merged: the ids then differ by a few tokens and so do
-    the features of the b-tokens that received them -- every such token is reported, and the bar is >= 99.9 % agreement."""
+    boundary of a LATER iteration may swap which of two a-tokens is merged: the ids then differ by one token per side and so
+    do the features of the two b-tokens that received them.  Round 6 pins what is MEASURED instead of a blanket 99.9 %: on every
+    named case of this file -- both forms of the fp32 match (tome_split 1 / 2 and the forced kernels), T up to 180 -- the kept ids
+    and all rows agree exactly (profiles/r06_tome_ties.txt); the bound is that plus ONE near-tie: `max_ids` ids per side,
+    `max_rows` rows.  Every disagreeing token is printed.  (The randomised fuzz passes its own, relative bound.)"""
     gi, gf = _tome_as_map(f.cpu(), i.cpu())
     xi, xf = _tome_as_map(ef, ei)
     if torch.equal(gi, xi):
-        err = float((gf.float() - xf.float()).abs().max())
-        assert err <= tol, f"{what}: feature max err {err:.3e}"
-        return 1.0, 1.0
+        err = (gf.float() - xf.float()).abs().amax(dim=1)
+        bad = int((err > tol).sum())
+        if bad:
+            print(f"{what}: ids equal; {bad} of {len(err)} rows differ (argmax near-ties), token ids {xi[err > tol][:8].tolist()}")
+        assert bad <= max_rows, f"{what}: {bad} rows differ in features (max {float(err.max()):.3e}); allowed {max_rows}"
+        return 1.0, 1.0 - bad / max(1, len(err))
     both = sorted(set(gi.tolist()) & set(xi.tolist()))
     only_g, only_x = sorted(set(gi.tolist()) - set(xi.tolist())), sorted(set(xi.tolist()) - set(gi.tolist()))
     sel = torch.tensor(both, dtype=torch.int64)
@@ -733,8 +789,8 @@ def _compare_tome(f, i, ef, ei, tol, what):
     id_agree, feat_agree = len(both) / len(xi), 1.0 - bad / max(1, len(both))
     print(f"{what}: near-tie: ids only here {only_g[:8]}, only in the oracle {only_x[:8]}; id agreement {id_agree:.5f}, "
           f"{bad} of {len(both)} common tokens differ in features (max {float(err.max()):.3e})")
-    assert id_agree >= 0.999, f"{what}: only {len(both)}/{len(xi)} token ids agree"
-    assert feat_agree >= 0.999, f"{what}: {bad} common tokens differ in features"
+    assert len(only_x) <= max_ids and len(only_g) <= max_ids, f"{what}: {len(only_x)} kept ids differ (allowed {max_ids})"
+    assert bad <= max_rows, f"{what}: {bad} common tokens differ in features (allowed {max_rows})"
     return id_agree, feat_agree
 
 
@@ -841,16 +897,17 @@ def test_tome_16bit_match_scores_against_dense_reference():
         assert same > 0.99 and agree > 0.97
 
 
-@pytest.mark.parametrize("T,ratio", [(180, 0.5), (128, 0.85)], ids=["C5_T180_r0.5", "T128_r0.85"])
-def test_tome_full_size_against_oracle(T, ratio):
+@pytest.mark.parametrize("T,ratio,n_head", [(180, 0.5, 1), (128, 0.85, 1), (128, 0.7, 4)], ids=["C5_T180_r0.5", "T128_r0.85", "T128_r0.7_4heads"])
+def test_tome_full_size_against_oracle(T, ratio, n_head):
     """BASELINE config 5 (run_vidqa.sh:44): ToMe `video` at the full clip length -- 35 280 tokens, one 17 640^2 x 1024 match.
-    Ratio 0.5 is positionally exact (every even token merges into an odd one); 0.85 runs three iterations."""
+    Ratio 0.5 is positionally exact (every even token merges into an odd one); 0.85 runs three iterations; n_head = 4 is the reference's
+    head-mean metric (`metric.mean(2)`, tome_token_merger.py:143-146) at full size.  Measured (round 6): 0 rows / ids differ in all three."""
     from oracle import sttm_oracle as O
     from sttm_amd import get_tome_features
     from sttm_amd.synth import synth_video
     x = synth_video(T, 1024, 14, 14, seed=7)
-    ef, ei = O.get_tome_features(x, ratio, "video", 1)
-    f, i = get_tome_features(x.to(_dev()), ratio, "video", 1)
+    ef, ei = O.get_tome_features(x, ratio, "video", n_head)
+    f, i = get_tome_features(x.to(_dev()), ratio, "video", n_head)
     assert f.shape == ef.shape and i.shape == ei.shape
     if ratio == 0.5:
         # kept ids are positionally exact.  Which b-token an a-token merges INTO is an argmax over 17 640 scores whose two best
@@ -860,7 +917,7 @@ def test_tome_full_size_against_oracle(T, ratio):
         err = (f.cpu() - ef).abs().amax(dim=1)
         bad = (err > FP32_TOL).nonzero().flatten()
         print(f"T={T} r=0.5: {len(bad)} of {len(err)} rows differ (argmax near-ties), token ids {ei[bad][:8].tolist()}")
-        assert len(bad) <= 0.001 * len(err), f"{len(bad)} rows differ"
+        assert len(bad) <= 2, f"{len(bad)} rows differ (measured 0; one argmax near-tie = 2 rows allowed)"
     else:
         _compare_tome(f, i, ef, ei, FP32_TOL, f"T={T} r={ratio}")
 
@@ -893,7 +950,8 @@ def test_tome_match_scores_against_dense_reference():
 
 
 TOME_DEFAULT_SPLIT = 2        # the library's default (three product terms; 1 = four terms)
-TOME_MATCH_MODES = {"fp32_mfma": 0, "split4_tile128": 3, "split4_tile256_dma": 4, "split3_tile128": 5, "split3_tile256_dma": 6}
+TOME_MATCH_MODES = {"fp32_mfma": 0, "split4_tile128": 3, "split4_tile256_dma": 4, "split3_tile128": 5, "split3_tile256_dma": 6,
+                    "split3_tile256_four_waves": 7}
 
 
 @pytest.mark.parametrize("mode", sorted(TOME_MATCH_MODES), ids=str)
@@ -1039,7 +1097,8 @@ def test_tome_fuzz_against_oracle():
                 else:
                     exact += 1
             else:
-                _compare_tome(f, i, ef, ei, FP32_TOL, what)
+                # (random shapes: the relative bound -- 0.1 % of the kept ids, at least one near-tie)
+                _compare_tome(f, i, ef, ei, FP32_TOL, what, max_ids=max(1, len(xi) // 1000), max_rows=max(2, len(xi) // 500))
                 near += 1
         print(f"tome fuzz: {exact} exact, {near} near-tie")
         assert exact >= 25

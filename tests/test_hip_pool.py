@@ -245,7 +245,7 @@ def test_fused_pooled_input_falls_back_and_rejects_like_get_2dpool():
     out = torch.empty(4 * 196, 96, device=DEV); npc = torch.empty(4 * 196, dtype=torch.int32, device=DEV)
     tl = torch.empty(4 * 196, 5, dtype=torch.int32, device=DEV); cnt = torch.zeros(8, dtype=torch.int32, device=DEV)
     args = lambda root, mode, stride: (d.data_ptr(), 4, 27, 27, 96, 0, mode, stride, 0.85, 0.55, root, 0, 0, ws.data_ptr(), ws.numel(),   # noqa: E731
-                                       out.data_ptr(), npc.data_ptr(), tl.data_ptr(), cnt.data_ptr(), None, 0, torch.cuda.current_stream().cuda_stream)
+                                       out.data_ptr(), npc.data_ptr(), tl.data_ptr(), cnt.data_ptr(), None, 0, torch.cuda.current_stream().cuda_stream, 0)
     assert lib.sttm_quadtree_merge_pooled(*args(0, 2, 2)) == _lib.ERR_UNSUPPORTED          # 4-level tree
     assert lib.sttm_quadtree_merge_pooled(*args(1, 0, 3)) == _lib.ERR_UNSUPPORTED          # 3 x 3 average window
     assert lib.sttm_quadtree_merge_pooled(*args(1, 2, 1)) == _lib.ERR_ARG                  # stride 1 = identity

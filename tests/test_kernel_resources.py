@@ -29,6 +29,7 @@ NO_SCRATCH = [
     ("K1 split form, pass B over one upper level (C4 grids)", r"k_spatial_upperIfLi4ELi1ELi256E"),
     ("K1 split form, pass B over three upper levels (6-level trees)", r"k_spatial_upperIfLi4ELi3ELi256E"),
     ("K2 fp32 (8-wide row packs)", r"k_pairs256IfLi8ELi5ELi32E"),
+    ("K2 fp32, the column walk's 16-byte packs (round 6: the headline's pair kernel)", r"k_pairs256IfLi4ELi5ELi32E"),
     ("K2 bf16", r"k_pairs256INS_6bf16_tELi8ELi5ELi64E"),
     ("K3 fused label stage", r"k_col_labelsILi2E"),
     ("K5 fp32", r"k_group_meanIfLi8ELi6E"),
@@ -38,6 +39,8 @@ NO_SCRATCH = [
     ("K1 on the unpooled token map (get_2dPool fused into the leaf load), fp32 C<=1024", r"k_spatial_pooledIfLi4ELi256E"),
     ("ToMe 256-tile match, fp32 two-plane", r"k_tome_match_gldsILi2ELi4E"),
     ("ToMe 256-tile match, one plane", r"k_tome_match_gldsILi1ELi1E"),
+    ("ToMe 256-tile match, four-wave form (accumulators = the whole AGPR file, named in inline assembly), fp32 two-plane", r"k_tome_match_gldsILi2ELi3ENS_5f16_tELi0ELi4E"),
+    ("ToMe 256-tile match, four-wave form, bf16", r"k_tome_match_gldsILi1ELi1ENS_6bf16_tELi0ELi4E"),
 ]
 
 
@@ -88,3 +91,42 @@ def test_headline_and_production_kernels_use_no_scratch(kernels, what, pattern):
     assert hits, f"no kernel matches {pattern!r} ({what}): the guard list is stale"
     spilled = {n: v for n, v in hits.items() if v[0] != 0}
     assert not spilled, f"{what}: scratch in use (bytes per lane, VGPRs): {spilled}"
+
+
+def test_four_wave_tome_kernels_keep_the_compiler_out_of_the_agprs():
+    """csrc/tome.hip, TomeAcc: the four-wave match kernels name their 256 accumulator registers literally in inline assembly; a compiler
+    spill into an AGPR (v_accvgpr_write) or a compiler copy out of one would corrupt / duplicate them silently.  The disassembly of the
+    built kernels must hold exactly the 256 v_accvgpr_read of TomeAcc::read (16 per block, one statement pair per block) and no
+    v_accvgpr_write / v_accvgpr_mov at all."""
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sttm_amd", "lib", "libsttm_hip.so")
+    if not os.path.exists(lib):
+        pytest.skip("library not built")
+    for tool in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump"):
+        if not os.path.exists(f"{LLVM}/{tool}"):
+            pytest.skip(f"{tool} not available")
+    found = 0
+    with tempfile.TemporaryDirectory() as tmp:
+        fat = os.path.join(tmp, "fat.bin")
+        subprocess.run([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", lib, os.path.join(tmp, "copy.so")], check=True)
+        blob = open(fat, "rb").read()
+        starts = [m.start() for m in re.finditer(re.escape(MAGIC), blob)]
+        for n, s0 in enumerate(starts):
+            e = starts[n + 1] if n + 1 < len(starts) else len(blob)
+            if b"k_tome_match_glds" not in blob[s0:e]:
+                continue
+            part, co = os.path.join(tmp, f"b{n}.bin"), os.path.join(tmp, f"b{n}.co")
+            with open(part, "wb") as fh:
+                fh.write(blob[s0:e])
+            r = subprocess.run([f"{LLVM}/clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                                f"--input={part}", f"--output={co}", "--unbundle"], capture_output=True, text=True)
+            if r.returncode != 0 or not os.path.exists(co) or os.path.getsize(co) == 0:
+                continue
+            dis = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--mcpu=gfx950", co], capture_output=True, text=True, check=True).stdout
+            for blk in re.split(r"\n(?=[0-9a-f]+ <)", dis):
+                head = blk.split("\n", 1)[0]
+                if "k_tome_match_glds" not in head or not re.search(r"ELi0ELi4EE", head):
+                    continue
+                found += 1
+                assert len(re.findall(r"v_accvgpr_read_b32", blk)) == 256, head
+                assert not re.search(r"v_accvgpr_write|v_accvgpr_mov", blk), head
+    assert found >= 3, "the four-wave ToMe match kernels (fp32 two-plane, bf16, fp16) are missing from the library"
