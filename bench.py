@@ -37,7 +37,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA = the fp32 
 MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/FP16 MFMA, dense (32x32x16)
 KERNELS = ["quadtree_spatial", "temporal_pairs_labels", "labels_standalone", "group_mean"]
 # fp16 product terms per fp32 ToMe score (the library's tome_split switch: 2 -> three terms, the default; 1 -> four)
-TOME_TERMS = {"1": 4, "2": 3, "3": 4, "4": 4, "5": 3, "6": 3}.get(os.environ.get("STTM_TOME_SPLIT", "2"), 4)
+TOME_TERMS = {"1": 4, "2": 3, "3": 4, "4": 4, "5": 3, "6": 3, "7": 3}.get(os.environ.get("STTM_TOME_SPLIT", "2"), 4)
 
 
 def parse():
@@ -261,6 +261,8 @@ def run_configs(dev, rank, world, timed, log):
 def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
+        if torch.cuda.is_available() and torch.cuda.device_count() < args.gpus:
+            sys.exit(f"bench.py --gpus {args.gpus}: this node has {torch.cuda.device_count()} GPU(s)")
         # plain `python bench.py --gpus N`: become the launcher of N ranks (one process per GPU, RCCL over xGMI)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
@@ -270,6 +272,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but the launcher started {world} ranks"
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    if torch.cuda.device_count() < args.gpus:
+        # fail fast and clearly (one process per GPU of ONE node: there is nothing to fall back to)
+        sys.exit(f"bench.py --gpus {args.gpus}: this node shows {torch.cuda.device_count()} GPU(s) to rank {rank}; "
+                 f"run with --gpus <= {torch.cuda.device_count()} or on a node with {args.gpus} MI355X")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     numa = pin_to_gpu_numa_node(local_rank) if os.environ.get("STTM_BENCH_NO_PIN") != "1" else None
@@ -559,7 +565,8 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import sttm_oracle as O
-        ncpu = os.cpu_count() or 1
+        host = host_cpu_facts()
+        ncpu = host["logical_cpus"]          # (the CPUs this process may run on: what torch can use, and what cpu_baseline reports)
         # the pool the GPU path was timed on + 16 further distinct synth-v1 videos: 24 videos checked index-exact against the oracle
         n_extra = 16
         sample_dev = [pool[i] for i in range(min(P, 8))]
@@ -599,7 +606,6 @@ def main():
                          if all(torch.equal(a, b) for a, b in zip((bf, bn, bt), get_quadtree_features(x, thr, tthr, root))))
         log(f"cpu baseline: {done} videos in {spent:.2f} s with {best_thr} threads; {match}/{checked} index-exact; batch == per-video on {batch_same}/{checked}")
         del sample_dev
-        host = host_cpu_facts()
         cpu = {"value": round(done / spent, 3), "unit": "videos/s", "cores": best_thr, "threads": best_thr,
                "cores_meaning": "torch intra-op threads the oracle ran on (the bench contract's `cores` = threads actually used); the host's "
                                 "physical core count is host_physical_cores",
@@ -614,6 +620,13 @@ def main():
         out = {
             "metric": "videos/sec (128-frame, 14x14x1024 tokens) STTM merge; merged-index match vs ref",
             "value": round(value, 2), "unit": "videos/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            # what `value` is (rounds 1-4: one video per call; since round 5 the batch entry point) and the other definition next to it,
+            # at top level, so that no consumer compares numbers of different definitions
+            "value_definition": ("batch entry point: get_quadtree_features_batch, %d independent videos per call (library-internal streams); "
+                                 "NOT the definition of rounds 1-4 -- compare those with value_one_call_per_video" % BATCH) if args.mode == "batch"
+                                else "one get_quadtree_features call per video on one stream (the reference's API; the definition of rounds 1-4)",
+            "value_one_call_per_video": (ext.get("dropin_one_call_per_video", {}).get("value") if args.mode == "batch" else round(value, 2)),
+            "value_batch_entry_point": (round(value, 2) if args.mode == "batch" else ext.get("batch_pipeline", {}).get("value")),
             "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synth-v1 T={T} 14x14x1024 fp32, STTM spatial 0.85 + temporal 0.55, root_level 1",

@@ -93,3 +93,19 @@ def test_bench_validate_mode_under_torchrun():
 def test_bench_refuses_a_world_size_that_differs_from_gpus():
     r = _torchrun(1, [os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--videos-per-step", "2", "--frames", "8"])
     assert r.returncode != 0 and "launcher started 1 ranks" in (r.stdout + r.stderr)
+
+
+def test_bench_fails_fast_when_the_node_has_fewer_gpus_than_asked_for():
+    """`python bench.py --gpus N` on a node with fewer than N GPUs: a clear message at once, before any launcher / rendezvous."""
+    import torch
+    n = torch.cuda.device_count()
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(n + 1), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and f"this node has {n} GPU" in (r.stdout + r.stderr)
+    # the value_definition / both-definitions fields of the JSON line (ADVICE round 5): a tiny run
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "1", "--warmup", "1", "--videos-per-step", "16", "--frames", "16",
+                        "--batch", "8", "--profile-calls", "8", "--no-cpu-baseline", "--no-configs"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert "batch entry point" in line["value_definition"] and line["value_batch_entry_point"] == line["value"]
+    assert line["value_one_call_per_video"] == line["dropin_one_call_per_video"]["value"] > 0

@@ -170,6 +170,45 @@ def test_bench_rank_logic_with_two_gloo_ranks(tmp_path):
     assert res[0]["job"]["elapsed_s"] == res[1]["job"]["elapsed_s"] and res[0]["job"]["value"] == res[1]["job"]["value"]
 
 
+def test_eight_ranks_mixed_clip_lengths_lpt_sharding_and_the_padded_index_gather(tmp_path):
+    """The node the north star names: 8 ranks.  19 videos of mixed lengths, LPT sharding on the frame counts (uneven ownership: some ranks
+    own three videos, some two), the count gather and the padded index gather -- every rank ends up with every video's result."""
+    costs = [9, 1, 4, 2, 6, 1, 1, 3, 5, 2, 2, 1, 7, 1, 3, 2, 1, 4, 1]
+    n_videos, world = len(costs), 8
+    owned = [shard_videos(n_videos, world, r, costs) for r in range(world)]
+    assert sorted(i for o in owned for i in o) == list(range(n_videos)) and len({len(o) for o in owned}) > 1
+    loads = [sum(costs[i] for i in o) for o in owned]
+    assert max(loads) - min(loads) <= max(costs)
+    mp.spawn(_worker, args=(world, _free_port(), n_videos, str(tmp_path), costs), nprocs=world, join=True)
+    from oracle import sttm_oracle as O
+    from sttm_amd.synth import synth_video
+    outs = [O.get_quadtree_features(synth_video(costs[v], 16, 14, 14, seed=v), 0.85, 0.55, 1) for v in range(n_videos)]
+    expect = torch.tensor([o[0].shape[0] for o in outs], dtype=torch.int32)
+    expect_idx = torch.full((n_videos, max(costs) * 196), -1, dtype=torch.int32)
+    for v, (_, _, t) in enumerate(outs):
+        expect_idx[v, :t.shape[0]] = t[:, 0] * 196 + t[:, 1] * 14 + t[:, 2]
+    for r in range(world):
+        assert torch.equal(torch.load(os.path.join(str(tmp_path), f"r{r}.pt")), expect)
+        assert torch.equal(torch.load(os.path.join(str(tmp_path), f"i{r}.pt")), expect_idx)
+
+
+def test_bench_rank_logic_with_eight_gloo_ranks(tmp_path):
+    """bench.py --gpus 8 without the GPUs: run_sharded_job on 8 CPU ranks (weak scaling: 8 x K x V videos, MAX of the elapsed time over the
+    ranks, one count gather)."""
+    world = 8
+    mp.spawn(_job_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    from oracle import sttm_oracle as O
+    from sttm_amd.synth import synth_video
+    res = [torch.load(os.path.join(str(tmp_path), f"j{r}.pt")) for r in range(world)]
+    K, V = 2, 3
+    expect = torch.tensor([O.get_quadtree_features(synth_video(2, 16, 14, 14, seed=g), 0.85, 0.55, 1)[0].shape[0] for g in range(world * K * V)],
+                          dtype=torch.int32)
+    for r in range(world):
+        assert res[r]["calls"] == [0, 0, 1] and res[r]["job"]["videos"] == world * K * V
+        assert torch.equal(res[r]["all"], expect) and res[r]["job"]["counts"] == expect[r::world].tolist()
+    assert len({res[r]["job"]["elapsed_s"] for r in range(world)}) == 1 and len({res[r]["job"]["value"] for r in range(world)}) == 1
+
+
 def test_run_sharded_job_single_process_needs_no_process_group():
     from sttm_amd.distributed import run_sharded_job
     seen = []
