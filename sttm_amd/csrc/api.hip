@@ -546,7 +546,7 @@ int merge_group(int nv, const void* const* x, int64_t stride_t, int64_t stride_c
     if (!ta.fold_labels) {
         // (the stage-skewed batch form runs `concurrent_sets` launch sets at once, and every one of them can sit in the fused label
         // kernel's grid barrier at the same time: the residency budget is shared between them)
-        if (sttm::labels_can_fuse(ta, nv * (concurrent_sets > 1 ? concurrent_sets : 1))) {
+        if (sttm::labels_can_fuse(ta, nv, concurrent_sets)) {
             if ((e = sttm::launch_labels_fused(ta, bp, nv, stream)) != hipSuccess)
                 return fail(STTM_ERR_LAUNCH, "fused label kernel: %s", hipGetErrorString(e));
         } else if ((e = sttm::launch_col_labels(ta, bp, nv, true, stream)) != hipSuccess ||

@@ -201,7 +201,7 @@ __device__ __forceinline__ void rebase(TemporalArgs& a, const BatchPtrs& bp, int
 hipError_t launch_pairs(const TemporalArgs& a, const BatchPtrs& bp, int n_videos, hipStream_t stream);
 hipError_t launch_slow_filter(const TemporalArgs& a, const BatchPtrs& bp, int n_videos, hipStream_t stream);
 hipError_t launch_col_labels(const TemporalArgs& a, const BatchPtrs& bp, int n_videos, bool probe, hipStream_t stream);
-bool labels_can_fuse(const TemporalArgs& a, int n_videos);
+bool labels_can_fuse(const TemporalArgs& a, int n_videos, int concurrent_sets = 1);
 bool labels_can_fold(const TemporalArgs& a, int n_videos, int* cap);
 hipError_t launch_labels_fused(const TemporalArgs& a, const BatchPtrs& bp, int n_videos, hipStream_t stream);
 hipError_t launch_group_mean(const TemporalArgs& a, const BatchPtrs& bp, int n_videos, hipStream_t stream);

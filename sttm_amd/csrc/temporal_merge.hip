@@ -1247,7 +1247,7 @@ hipError_t launch_col_labels(const TemporalArgs& a, const BatchPtrs& bp, int n_v
 // an in-kernel grid barrier.  Residency: R workgroups against what the occupancy calculator says the device holds of this
 // kernel with this much LDS (it is one workgroup per CU for the large-LDS shapes) -- a partitioned device (CPX mode,
 // 32 CUs) or a smaller part simply takes the two-launch path.
-bool labels_can_fuse(const TemporalArgs& a, int n_videos) {
+bool labels_can_fuse(const TemporalArgs& a, int n_videos, int concurrent_sets) {
     if (a.no_fuse) return false;
     const int cus = device_cus();
     if (cus <= 0) return false;
@@ -1271,8 +1271,11 @@ bool labels_can_fuse(const TemporalArgs& a, int n_videos) {
         per_cu = it->second;
     }
     if (per_cu < 1) return false;
-    // a quarter of what the API promises: it answers one block per CU too many for kernels with > 80 SGPRs
-    // (MI355X_MICROARCH.md, residency), and other streams may hold part of the device
+    // The API answers one block per CU too many for kernels with > 80 SGPRs (MI355X_MICROARCH.md, residency): half of what it promises is
+    // safe from per_cu = 2 on.  Who else holds CUs: the stage-skewed batch form says how many launch sets can sit in this kernel's grid
+    // barrier at once (`concurrent_sets`: they share the budget -- round-5 advisor finding); a lone call knows nothing about the caller's
+    // other streams and keeps the quarter it always took.
+    if (concurrent_sets > 1) return (long long)a.R * n_videos * concurrent_sets <= (long long)per_cu * cus / 2;
     return (long long)a.R * n_videos <= (long long)per_cu * cus / 4;
 }
 
