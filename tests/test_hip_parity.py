@@ -1037,7 +1037,8 @@ def test_tome_first_maximum_on_exact_ties(dtype):
             first = torch.full((8,), na, dtype=torch.long)
             for k, js in copies.items():
                 first[k] = int(js[0])
-            for mode, flat in [(m, 1) for m in ((0, 3, 4, 5, 6) if dtype == torch.float32 else (3, 4))] + [(4, 2), (4, 0)]:
+            # (7 = the four-wave form of the 256-tile kernel: per-block inside / partial decision, -inf for candidates past nb)
+            for mode, flat in [(m, 1) for m in ((0, 3, 4, 5, 6, 7) if dtype == torch.float32 else (3, 4, 7))] + [(4, 2), (4, 0), (7, 2), (7, 0)]:
                 _lib.configure(tome_split=mode, tome_flat=flat)
                 r = n // 2
                 nbytes = lib.sttm_tome_workspace_bytes(n, C, 1)
@@ -1212,9 +1213,9 @@ def test_tome_rank_by_counting_and_radix_sort_paths_are_bit_identical(dtype):
         _lib.configure(tome_rank=0)
 
 
-@pytest.mark.parametrize("mode", [3, 4], ids=["tile128", "tile256_dma"])
+@pytest.mark.parametrize("mode", [3, 4, 7], ids=["tile128", "tile256_dma", "tile256_four_waves"])
 def test_tome_16bit_match_kernel_variants(mode):
-    """Both 16-bit match kernels against the reference's vectors (bf16 / fp16 golden cases) and the oracle."""
+    """The 16-bit match kernels against the reference's vectors (bf16 / fp16 golden cases) and the oracle."""
     from oracle import sttm_oracle as O
     from sttm_amd import _lib, get_tome_features
     from sttm_amd.synth import synth_video
