@@ -309,9 +309,17 @@ def main():
 
     BATCH = max(1, args.batch)
 
+    # caller-owned output blocks for the batch entry point (ABI v8 `out=`): allocated ONCE, reused by every call -- what a pipeline that
+    # consumes a call's results before issuing the next one does; no 10 GB of worst-case rows per call through the allocator
+    out_blocks = None
+    if args.mode == "batch" or not args.no_extensions:
+        nb_ = min(BATCH, V)
+        out_blocks = (torch.empty((nb_, T * H * W, C), device=dev), torch.empty((nb_, T * H * W), dtype=torch.int32, device=dev),
+                      torch.empty((nb_, T * H * W, 5), dtype=torch.int32, device=dev))
+
     def run_step_batch(s, sink):
         for b0 in range(0, V, BATCH):
-            outs = get_quadtree_features_batch([pool[(s * V + v) % P] for v in range(b0, min(V, b0 + BATCH))], thr, tthr, root)
+            outs = get_quadtree_features_batch([pool[(s * V + v) % P] for v in range(b0, min(V, b0 + BATCH))], thr, tthr, root, out=out_blocks)
             sink.extend(o[0].shape[0] for o in outs)
 
     def barrier():
@@ -633,7 +641,7 @@ def main():
                        "videos_per_step": V, "pool_per_gpu": P, "global_videos": videos, "parallelism": f"videos sharded x{world}",
                        "mode": args.mode,
                        "api": (f"get_quadtree_features_batch: {BATCH} independent videos per call -> sttm_quadtree_merge_batch deals them out to the "
-                               "library's internal streams (whole per-video kernel chains, stage-skewed); every video's outputs incl. its host-visible "
+                               "library's internal streams (whole per-video kernel chains, stage-skewed), written into caller-owned output blocks (out=, allocated once); every video's outputs incl. its host-visible "
                                "token count N' are produced, bit-identical to one call per video (tests/test_hip_parity.py::"
                                "test_batched_extension_equals_per_video_calls); the one-call-per-video rate of rounds 1-4 is under "
                                "dropin_one_call_per_video") if args.mode == "batch" else
