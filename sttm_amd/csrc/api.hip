@@ -59,7 +59,11 @@ Config& config() {
         d.col_frames = env_int("STTM_COL_FRAMES", 8);
         d.col_cap = env_int("STTM_COL_CAP", 0);            // 0 = what the LDS budget allows
         d.col_pb = env_int("STTM_COL_PB", 0);
-        d.col_abl = env_int("STTM_COL_ABL", 0);
+#ifdef STTM_DEV
+        d.col_abl = env_int("STTM_COL_ABL", 0);          // development build: ablation bits of the column walk (outputs invalid)
+#else
+        d.col_abl = 0;
+#endif
         d.pair_vec = env_int("STTM_PAIR_VEC", 0);          // 0 = the column walk's width where it could run (see merge_group); -1 = the row kernels' width (rounds 1-5)
         return d;
     }();
@@ -639,7 +643,11 @@ int sttm_configure(const char* key, int value) {
         {"pairs_seg", &c.pairs_seg}, {"pairs_nt", &c.pairs_nt}, {"pairs_var", &c.pairs_var}, {"k1_var", &c.k1_var}, {"k1_split", &c.k1_split}, {"no_dense", &c.no_dense}, {"gm_split", &c.gm_split}, {"label_nt", &c.label_nt},
         {"vec16", &c.vec16}, {"vec32", &c.vec32}, {"fold_kb", &c.fold_kb}, {"fold_labels", &c.fold_labels}, {"no_fuse", &c.no_fuse}, {"tome_split", &c.tome_split}, {"tome_flat", &c.tome_flat}, {"tome_rank", &c.tome_rank},
         {"force_gmem_labels", &c.force_gmem_labels}, {"batch_streams", &c.batch_streams}, {"batch_sub", &c.batch_sub},
-        {"col_walk", &c.col_walk}, {"col_frames", &c.col_frames}, {"col_cap", &c.col_cap}, {"col_pb", &c.col_pb}, {"col_abl", &c.col_abl}, {"pair_vec", &c.pair_vec},
+        {"col_walk", &c.col_walk}, {"col_frames", &c.col_frames}, {"col_cap", &c.col_cap}, {"col_pb", &c.col_pb},
+#ifdef STTM_DEV
+        {"col_abl", &c.col_abl},
+#endif
+        {"pair_vec", &c.pair_vec},
     };
     for (auto& k : keys)
         if (!strcmp(key, k.name)) { *k.slot = value; return STTM_OK; }

@@ -112,7 +112,7 @@ struct ColWalkArgs {
     int frames;               // frames per workgroup (a chunk that does not start the clip reads one warm-up frame more)
     int cap;                  // node rows of the frame before kept in LDS (the rest is re-read from S / x)
     int pb;                   // candidate pairs per round of partial products
-    int abl;                  // ablation bits for measurements (outputs invalid): 1 = no pair phase, 2 = no row stash, 4 = no warm-up frame
+    int abl;                  // DEVELOPMENT build only (the product compiles it out): ablation bits for measurements, outputs invalid -- 1 = no pair phase, 2 = no row stash, 4 = no warm-up frame
 };
 constexpr int kColStatRow = 44;       // floats per wave of the statistics table (TreeConst<3>::NSTAT, checked in spatial_col.inc)
 // LDS of a column-walk workgroup (spatial_col.inc carves it in this order): node rows | 2 x 16 inverse norms, 2 x 16 + 16 pair descriptors,

@@ -127,6 +127,10 @@ def test_configure_accepts_known_keys_only():
     assert lib.sttm_configure(b"fold_labels", 0) == 0 and lib.sttm_configure(b"fold_kb", 20) == 0
     assert lib.sttm_configure(b"does_not_exist", 1) == _lib.ERR_ARG
     assert "does_not_exist" in _lib.last_error()
+    # switches that make outputs invalid (ablations) are development-build keys: the product library does not know them
+    assert lib.sttm_configure(b"col_abl", 1) == _lib.ERR_ARG
+    for key in (b"col_walk", b"col_frames", b"col_cap", b"col_pb", b"pair_vec"):
+        assert lib.sttm_configure(key, 0) == 0
 
 
 def test_product_library_has_no_measurement_hooks():

@@ -1,7 +1,7 @@
 """Column-walk spatial stage (csrc/spatial_col.inc) against the spatial + pair kernels in the batch entry point: videos/s under
 library switches, interleaved in ONE process on one box (same-box A/B).  Run on the GPU box:
     python tools/colwalk_sweep.py ["key=v,key=v" ...]        (default: a built-in list)
-Environment: T, C, DT (f32 / bf16), N (videos per timing), REPS."""
+Environment: T, C, DT (f32 / bf16), N (videos per timing), REPS; STTM_LIB=dev (python -m sttm_amd.build --dev) for the col_abl ablation bits."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,7 +14,9 @@ T, C = int(os.environ.get("T", "128")), int(os.environ.get("C", "1024"))
 dt = torch.float32 if os.environ.get("DT", "f32") == "f32" else torch.bfloat16
 N, REPS, P, CALL = int(os.environ.get("N", "1536")), int(os.environ.get("REPS", "3")), 8, 96
 pool = [synth_video(T, C, 14, 14, seed=100 + i, dtype=dt, device=dev, gen_device=dev) for i in range(P)]
-DEFAULT = dict(col_walk=1, col_frames=8, col_cap=0, col_pb=0, col_abl=0, batch_streams=3, batch_sub=8)
+DEFAULT = dict(col_walk=1, col_frames=8, col_cap=0, col_pb=0, batch_streams=3, batch_sub=8)
+if os.environ.get("STTM_LIB") == "dev":                 # the ablation bits (col_abl) exist in the development build only
+    DEFAULT["col_abl"] = 0
 _lib.configure(col_walk=0)
 ref = [get_quadtree_features(v, 0.85, 0.55, 1) for v in pool]
 torch.cuda.synchronize()
