@@ -267,8 +267,6 @@ int sttm_quadtree_merge_batch(int n_videos, const void* const* x, int64_t stride
  *   "tome_flat"   256-tile ToMe match kernels: 1 (default) spread all tile products evenly over one workgroup per CU when that
  *                 shortens the per-CU critical path against the best per-a-tile split (69 x 69 tiles at T = 180: 19 instead of 23
  *                 products per workgroup), 0 never, 2 always.  Same scores, same first-maximum argmax.
- *   "tome_rank"   ToMe ranking of the a-tokens: 0 (default) by counting in one kernel for clips of up to 49 152 a-tokens, 1 always the
- *                 radix sort path (A/B, tests).  Same order: descending best score, ties to the smaller token index.
  */
 int sttm_configure(const char* key, int value);
 
@@ -311,6 +309,8 @@ int sttm_merge_dst_idx(const int32_t* pairs, int L, int N, int32_t* rep_out, voi
  *              in original order with its merged sources folded in (size-weighted average, sources added in rank order)
  *   node_max_out / node_idx_out   optional [ceil(n/2)] copies of scores.max(-1) (:36) for inspection, may be NULL
  * Enqueued on `stream` without any host synchronisation; workspace >= sttm_tome_workspace_bytes(n, C, n_head).
+ * Limit: the unit-row matrix of one token half, ceil(n/2) x (C / n_head rounded up to 64) x 4 bytes, must stay below 2 GiB (fp32
+ * C = 1024: a million tokens); beyond it sttm_tome_workspace_bytes returns 0 and sttm_tome_step STTM_ERR_UNSUPPORTED.
  * ------------------------------------------------------------------------------------------------ */
 size_t sttm_tome_workspace_bytes(int n, int C, int n_head);
 int sttm_tome_step(const void* x, const float* size, const int64_t* idx, int n, int C, int n_head, int r, int dtype,

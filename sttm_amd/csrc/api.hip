@@ -24,7 +24,7 @@ int fail(int code, const char* fmt, ...) {
 // Tuning / test switches: defaults from STTM_<KEY> environment variables, read ONCE; sttm_configure overrides them.
 // None of them changes results.
 struct Config {
-    int pairs_seg, pairs_nt, pairs_var, k1_var, k1_split, no_dense, gm_split, label_nt, vec16, vec32, fold_kb, fold_labels, no_fuse, force_gmem_labels, tome_split, tome_flat, tome_rank,
+    int pairs_seg, pairs_nt, pairs_var, k1_var, k1_split, no_dense, gm_split, label_nt, vec16, vec32, fold_kb, fold_labels, no_fuse, force_gmem_labels, tome_split, tome_flat,
         batch_streams, batch_sub, col_walk, col_frames, col_cap, col_pb, col_abl, pair_vec;
 };
 int env_int(const char* name, int dflt) {
@@ -50,7 +50,6 @@ Config& config() {
         d.force_gmem_labels = env_int("STTM_FORCE_GMEM_LABELS", 0);
         d.tome_split = env_int("STTM_TOME_SPLIT", 2);
         d.tome_flat = env_int("STTM_TOME_FLAT", 1);
-        d.tome_rank = env_int("STTM_TOME_RANK", 0);
         d.batch_streams = env_int("STTM_BATCH_STREAMS", 3);
         d.batch_sub = env_int("STTM_BATCH_SUB", 8);
         // the column-walk spatial stage (spatial_col.inc): 0 = never (default: measured slower than the spatial + pair kernels although it
@@ -602,7 +601,6 @@ SidePool* side_pool(int want) {
 namespace sttm {
 int tome_split_mode() { return config().tome_split; }
 int tome_flat_mode() { return config().tome_flat; }
-int tome_rank_mode() { return config().tome_rank; }
 }  // namespace sttm
 
 extern "C" {
@@ -641,7 +639,7 @@ int sttm_configure(const char* key, int value) {
     Config& c = config();
     struct { const char* name; int* slot; } keys[] = {
         {"pairs_seg", &c.pairs_seg}, {"pairs_nt", &c.pairs_nt}, {"pairs_var", &c.pairs_var}, {"k1_var", &c.k1_var}, {"k1_split", &c.k1_split}, {"no_dense", &c.no_dense}, {"gm_split", &c.gm_split}, {"label_nt", &c.label_nt},
-        {"vec16", &c.vec16}, {"vec32", &c.vec32}, {"fold_kb", &c.fold_kb}, {"fold_labels", &c.fold_labels}, {"no_fuse", &c.no_fuse}, {"tome_split", &c.tome_split}, {"tome_flat", &c.tome_flat}, {"tome_rank", &c.tome_rank},
+        {"vec16", &c.vec16}, {"vec32", &c.vec32}, {"fold_kb", &c.fold_kb}, {"fold_labels", &c.fold_labels}, {"no_fuse", &c.no_fuse}, {"tome_split", &c.tome_split}, {"tome_flat", &c.tome_flat},
         {"force_gmem_labels", &c.force_gmem_labels}, {"batch_streams", &c.batch_streams}, {"batch_sub", &c.batch_sub},
         {"col_walk", &c.col_walk}, {"col_frames", &c.col_frames}, {"col_cap", &c.col_cap}, {"col_pb", &c.col_pb},
 #ifdef STTM_DEV

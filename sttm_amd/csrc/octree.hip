@@ -12,10 +12,9 @@
 //                 (the stop decision of a cell does not depend on the frontier, so every level is decided in full)
 //   k_oct_emit    one thread per leaf: walks its ancestors top-down to the first stopped one; the leaf that is that node's
 //                 first corner marks the node (origin addressing: the marks are already in output order)
-//   hipcub scan   exclusive sum of the marks = output rows, N' to the caller's device counter
+//   k_oct_scan_*  exclusive sum of the marks = output rows (4096 marks per workgroup, then the workgroup offsets), N' to the caller's
+//                 device counter
 //   k_oct_gather  one wave per marked leaf: copies the node's row from its pyramid level
-#include <hipcub/hipcub.hpp>
-
 #include "sttm_kernels.h"
 
 namespace sttm {
@@ -166,17 +165,69 @@ __global__ void __launch_bounds__(256) k_oct_gather(OctArgs a) {
     }
 }
 
-__global__ void k_oct_count(OctArgs a) {
-    const int S = a.side[a.L - 1];
-    const int64_t last = (int64_t)a.B * S * S * S - 1;
-    *a.count_out = a.rows[last] + a.mark[last];
+// Exclusive sum of the leaf marks (round 6: in-tree, it was hipcub::DeviceScan + a one-thread count kernel).  Pass 1: a workgroup scans
+// 4096 marks (four per thread, wave prefix by lane shifts, wave totals through LDS) and leaves its total in blocksum[b]; pass 2: workgroup b
+// adds the sum of the totals before it (a few hundred at most: one strided read + a workgroup reduction) and the last one writes N'.
+constexpr int OS_T = 1024, OS_PER = 4, OS_BLK = OS_T * OS_PER;
+__global__ void __launch_bounds__(OS_T) k_oct_scan_local(const int32_t* __restrict__ mark, int32_t* __restrict__ rows, int64_t n,
+                                                         int32_t* __restrict__ blocksum) {
+    __shared__ int wsum[OS_T / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t base = (int64_t)blockIdx.x * OS_BLK + (int64_t)tid * OS_PER;
+    int v[OS_PER];
+#pragma unroll
+    for (int k = 0; k < OS_PER; ++k) v[k] = base + k < n ? mark[base + k] : 0;
+    int total = 0;
+#pragma unroll
+    for (int k = 0; k < OS_PER; ++k) total += v[k];
+    int inc = total;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int pre = inc - total;
+    for (int w = 0; w < wave; ++w) pre += wsum[w];
+#pragma unroll
+    for (int k = 0; k < OS_PER; ++k) {
+        if (base + k < n) rows[base + k] = pre;
+        pre += v[k];
+    }
+    if (tid == OS_T - 1) blocksum[blockIdx.x] = pre;
 }
 
-size_t octree_scan_bytes(int64_t n) {
-    size_t bytes = 0;
-    hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const int32_t*)nullptr, (int32_t*)nullptr, (int)n);
-    return bytes;
+__global__ void __launch_bounds__(OS_T) k_oct_scan_add(const int32_t* __restrict__ mark, int32_t* __restrict__ rows, int64_t n,
+                                                       const int32_t* __restrict__ blocksum, int32_t* __restrict__ count_out) {
+    __shared__ int wsum[OS_T / 64];
+    __shared__ int off_sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int part = 0;
+    for (int b = tid; b < (int)blockIdx.x; b += OS_T) part += blocksum[b];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+    if (lane == 0) wsum[wave] = part;
+    __syncthreads();
+    if (tid == 0) {
+        int o = 0;
+        for (int w = 0; w < OS_T / 64; ++w) o += wsum[w];
+        off_sh = o;
+    }
+    __syncthreads();
+    const int off = off_sh;
+    const int64_t base = (int64_t)blockIdx.x * OS_BLK + (int64_t)tid * OS_PER;
+#pragma unroll
+    for (int k = 0; k < OS_PER; ++k) {
+        if (base + k < n) {
+            const int rw = rows[base + k] + off;
+            if (off) rows[base + k] = rw;
+            if (base + k == n - 1) *count_out = rw + mark[n - 1];
+        }
+    }
 }
+
+size_t octree_scan_bytes(int64_t n) { return (size_t)((n + OS_BLK - 1) / OS_BLK) * sizeof(int32_t); }
 
 template <typename T>
 static hipError_t octree_run_t(OctArgs& a, int vec, void* scan_tmp, size_t scan_bytes, hipStream_t stream) {
@@ -207,8 +258,10 @@ static hipError_t octree_run_t(OctArgs& a, int vec, void* scan_tmp, size_t scan_
     const int S = a.side[a.L - 1];
     const int64_t leaves = (int64_t)a.B * S * S * S;
     hipLaunchKernelGGL(k_oct_emit, dim3(grid_for(leaves)), dim3(256), 0, stream, a);
-    hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, a.mark, a.rows, (int)leaves, stream);
-    hipLaunchKernelGGL(k_oct_count, dim3(1), dim3(1), 0, stream, a);
+    const unsigned scan_blocks = (unsigned)((leaves + OS_BLK - 1) / OS_BLK);
+    if ((size_t)scan_blocks * sizeof(int32_t) > scan_bytes) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_oct_scan_local, dim3(scan_blocks), dim3(OS_T), 0, stream, a.mark, a.rows, leaves, reinterpret_cast<int32_t*>(scan_tmp));
+    hipLaunchKernelGGL(k_oct_scan_add, dim3(scan_blocks), dim3(OS_T), 0, stream, a.mark, a.rows, leaves, reinterpret_cast<const int32_t*>(scan_tmp), a.count_out);
     STTM_OCT_VEC(k_oct_gather, dim3(grid_for(leaves * 64)), dim3(256), 0, stream, a);
 #undef STTM_OCT_VEC
     return hipGetLastError();

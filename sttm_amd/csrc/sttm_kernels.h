@@ -212,7 +212,6 @@ size_t colscratch_ints(int T, int H, int W, int R);
 void pairs_shape(int T, int R, int fold, int want_seg, int want_nt, int* seg, int* nt);
 
 int tome_flat_mode();        // 256-tile ToMe match kernels: 1 = tile products spread evenly over the CUs when that is shorter, 0 = never, 2 = always
-int tome_rank_mode();        // 0 = ranking by counting (clips of up to 49 152 a-tokens), 1 = always the radix sort path (A/B, tests)
 int tome_split_mode();       // 0 = fp32-input MFMA match kernel; > 0 = fp16 two-plane split variants (api.hip: Config)
 
 hipError_t launch_pool2d(const void* x, void* out, int T, int H, int W, int C, int OH, int OW, int stride, int mode, int dtype,

@@ -8,11 +8,9 @@
 //                      TRANSPOSED tile D[j][i] = b_j . a_i, so every lane owns one a-row i and sees its
 //                      candidates j along its accumulator registers: the running max/argmax needs no
 //                      cross-lane traffic inside the main loop.
-//   hipcub radix sort  ranking of the a-tokens by best score, descending (stable)
+//   k_tome_rank        ranking of the a-tokens by best score, descending, ties to the smaller index: by counting (any clip length)
 //   k_tome_*           per-destination source lists in rank order, then the size-weighted merge
 // Nothing here depends on data-dependent sizes: the step is enqueued without any host synchronisation.
-#include <hipcub/hipcub.hpp>
-
 #include "sttm_kernels.h"
 
 namespace sttm {
@@ -106,6 +104,77 @@ __device__ __forceinline__ void tome_running_max(const tome_f32x16 (&acc)[PJ][QI
     }
 }
 
+// ---- the two-pass running max of the 256-tile kernels (round 6) -----------------------------------------------------------------
+// The sweep above costs ~5 VALU instructions per score (round to the input dtype, compare, two selects) -- 128 scores per lane and tile
+// product, with both waves of a SIMD in their epilogue at the same time (nothing to overlap it with).  Rounding is monotone, so
+//   max_j rnd(s_j) = rnd(max_j s_j)   and   {j : rnd(s_j) = R} = {j : s_j >= theta(R)},  theta(R) = the smallest float that rounds to R:
+// pass 1 is a plain fp32 maximum (v_max3_f32: half an instruction per score), ONE rounding per row, and -- only if some lane of the wave
+// improves STRICTLY on its running maximum -- pass 2 finds the first candidate at or above theta (compare + select).  Same bits as the
+// sweep: a candidate wins iff its rounded score is strictly above the running maximum, ties go to the smallest j, NaN scores never win.
+template <typename RT> __device__ __forceinline__ float tome_round_as(float f);
+template <> __device__ __forceinline__ float tome_round_as<float>(float f) { return f; }
+template <> __device__ __forceinline__ float tome_round_as<bf16_t>(float f) { return bf16_bits_to_float(float_to_bf16_bits(f)); }
+template <> __device__ __forceinline__ float tome_round_as<f16_t>(float f) { return f16_bits_to_float(float_to_f16_bits(f)); }
+// theta(R) for a value R of the 16-bit type: the midpoint between R and its neighbour below (in VALUE; found on the 16-bit pattern, so
+// subnormals and binade boundaries need no cases), which is exact in fp32, and belongs to R iff R's pattern is even (round to nearest even)
+template <typename RT> __device__ __forceinline__ float tome_tie_floor(float r) {
+    if constexpr (std::is_same<RT, float>::value) {
+        return r;
+    } else {
+        uint32_t h, mag;
+        if constexpr (std::is_same<RT, bf16_t>::value) h = float_to_bf16_bits(r); else h = float_to_f16_bits(r);
+        mag = h & 0x7fffu;
+        const bool down = mag == 0u || (h & 0x8000u);                    // R <= 0: the neighbour below has the larger magnitude
+        const uint32_t other = down ? mag + 1u : mag - 1u;
+        float fm, fo;
+        if constexpr (std::is_same<RT, bf16_t>::value) { fm = bf16_bits_to_float(mag); fo = bf16_bits_to_float(other); }
+        else { fm = f16_bits_to_float(mag); fo = f16_bits_to_float(other); }
+        const uint32_t mid = __float_as_uint(0.5f * (fm + fo));
+        const uint32_t odd = mag & 1u;
+        return __uint_as_float(down ? ((mid - odd) | 0x80000000u) : mid + odd);
+    }
+}
+__device__ __forceinline__ float tome_max3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));          // (no canonicalising v_max_f32 x, x per operand)
+    return d;
+}
+template <typename RT, int QI, int PJ>
+__device__ __forceinline__ void tome_running_max2(const tome_f32x16 (&acc)[PJ][QI], float (&bestv)[QI], int (&bestj)[QI], int jlane, int nb,
+                                                  bool inside) {
+    static_assert(PJ != 4, "the four-wave kernel has its own running max (tome_running_max2_agpr)");
+#pragma unroll
+    for (int q = 0; q < QI; ++q) {
+        float v[PJ * 16];
+#pragma unroll
+        for (int p = 0; p < PJ; ++p)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[p * 16 + e] = acc[p][q][e];
+        if (!inside) {
+#pragma unroll
+            for (int p = 0; p < PJ; ++p)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[p * 16 + e] = jlane + p * 32 + (e & 3) + 8 * (e >> 2) < nb ? v[p * 16 + e] : -INFINITY;
+        }
+        float m = tome_max3(v[0], v[1], v[2]);
+#pragma unroll
+        for (int e = 3; e + 1 < PJ * 16; e += 2) m = tome_max3(m, v[e], v[e + 1]);
+        m = tome_max3(m, v[PJ * 16 - 1], v[PJ * 16 - 1]);
+        const float r = tome_round_as<RT>(m);
+        const bool gt = r > bestv[q];
+        if (__builtin_amdgcn_ballot_w64(gt) != 0ull) {
+            const float theta = tome_tie_floor<RT>(r);
+            int bc = 0;
+#pragma unroll
+            for (int p = PJ - 1; p >= 0; --p)
+#pragma unroll
+                for (int e = 15; e >= 0; --e) bc = v[p * 16 + e] >= theta ? p * 32 + (e & 3) + 8 * (e >> 2) : bc;
+            bestj[q] = gt ? jlane + bc : bestj[q];
+            bestv[q] = gt ? r : bestv[q];
+        }
+    }
+}
+
 template <typename T, int B> struct TomeAcc;
 template <int N, typename F> __device__ __forceinline__ void tome_static_for(F&& f);
 // The four-wave kernel's running max: block (p, q) of the AGPR accumulators is copied to 16 VGPRs and swept, one block at a time.
@@ -143,6 +212,46 @@ __device__ __forceinline__ void tome_running_max_agpr(float (&bestv)[QI], int (&
         });
         bestj[q] = bc >= 0 ? jlane + bc : bestj[q];
         bestv[q] = bv;
+    });
+}
+
+// The same two passes over the AGPR accumulators of the four-wave kernel: pass 1 copies one block of 16 at a time and folds it into the
+// row maximum, pass 2 (only when some lane improves) copies the blocks again, last block first.
+template <typename T, typename RT, int QI, int PJ>
+__device__ __forceinline__ void tome_running_max2_agpr(float (&bestv)[QI], int (&bestj)[QI], int jlane, int jwave, int nb) {
+    tome_static_for<QI>([&](auto Q) {
+        constexpr int q = decltype(Q)::value;
+        float m = -INFINITY;
+        tome_static_for<PJ>([&](auto P) {
+            constexpr int p = decltype(P)::value;
+            float o[16];
+            TomeAcc<T, p * QI + q>::read(o);
+            if (jwave + p * 32 + 32 > nb) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[e] = jlane + p * 32 + (e & 3) + 8 * (e >> 2) < nb ? o[e] : -INFINITY;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) m = tome_max3(m, o[e], o[e + 1]);
+        });
+        const float r = tome_round_as<RT>(m);
+        const bool gt = r > bestv[q];
+        if (__builtin_amdgcn_ballot_w64(gt) != 0ull) {
+            const float theta = tome_tie_floor<RT>(r);
+            int bc = 0;
+            tome_static_for<PJ>([&](auto P) {
+                constexpr int p = PJ - 1 - decltype(P)::value;
+                float o[16];
+                TomeAcc<T, p * QI + q>::read(o);
+                if (jwave + p * 32 + 32 > nb) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) o[e] = jlane + p * 32 + (e & 3) + 8 * (e >> 2) < nb ? o[e] : -INFINITY;
+                }
+#pragma unroll
+                for (int e = 15; e >= 0; --e) bc = o[e] >= theta ? p * 32 + (e & 3) + 8 * (e >> 2) : bc;
+            });
+            bestj[q] = gt ? jlane + bc : bestj[q];
+            bestv[q] = gt ? r : bestv[q];
+        }
     });
 }
 
@@ -702,7 +811,7 @@ __global__ void __launch_bounds__(128 * (8 / PJ), PJ == 4 ? 1 : 2) k_tome_match_
     if (S <= 0) return;
 
     const int prow = lane / CPR;
-    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(ap), 0, NP * na * D * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(ap), 0, NP * na * D * 2, 0x00020000);      // (< 2 GiB: tome_plan)
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(bp), 0, NP * nb * D * 2, 0x00020000);
     const uint32_t dma_voff = (uint32_t)((prow * D + ((lane % CPR) ^ ((4 * wave + prow / R256) & (CPR - 1))) * 8) * 2);
     // Round 6: buffer-addressed DMA with a RUNNING stage state.  The piece's first row and k0 are a SCALAR byte offset, every lane
@@ -873,12 +982,20 @@ __global__ void __launch_bounds__(128 * (8 / PJ), PJ == 4 ? 1 : 2) k_tome_match_
             // end of a tile product: running max (split: on the scaled scores, the factor 2^-24 is applied once at the end)
             const int prod = p_lo + st / NK, it = prod / jtiles, jt = prod - it * jtiles;
             const int j0 = jt * TG_T;
-            auto rnd_fn = [](float v) { return NP == 1 ? tome_round<T>(v) : v; };
-            if constexpr (PJ == 4) {
+            typedef typename std::conditional<NP == 1, T, float>::type RT;           // scores are rounded to the input dtype; split planes: fp32
+            if constexpr (ABL == 8) {                                                 // (development builds: the one-pass sweep, for the A/B)
+                auto rnd_fn = [](float v) { return tome_round_as<RT>(v); };
+                if constexpr (PJ == 4) {
+                    tome_mfma_drain();
+                    tome_running_max_agpr<T, QI, PJ>(bestv, bestj, j0 + wj * 32 * PJ + 4 * lhalf, j0 + wj * 32 * PJ, nb, rnd_fn);
+                } else {
+                    tome_running_max<QI, decltype(rnd_fn), NACC>(acc, bestv, bestj, j0 + wj * 32 * PJ + 4 * lhalf, nb, j0 + TG_T <= nb, rnd_fn);
+                }
+            } else if constexpr (PJ == 4) {
                 tome_mfma_drain();
-                if (ABL != 7) tome_running_max_agpr<T, QI, PJ>(bestv, bestj, j0 + wj * 32 * PJ + 4 * lhalf, j0 + wj * 32 * PJ, nb, rnd_fn);
+                if (ABL != 7) tome_running_max2_agpr<T, RT, QI, PJ>(bestv, bestj, j0 + wj * 32 * PJ + 4 * lhalf, j0 + wj * 32 * PJ, nb);
             } else {
-                tome_running_max<QI, decltype(rnd_fn), NACC>(acc, bestv, bestj, j0 + wj * 32 * PJ + 4 * lhalf, nb, ABL != 3 && j0 + TG_T <= nb, rnd_fn);
+                tome_running_max2<RT, QI, NACC>(acc, bestv, bestj, j0 + wj * 32 * PJ + 4 * lhalf, nb, ABL != 3 && j0 + TG_T <= nb);
             }
             clear_acc();
             if (st + 1 == S || jt + 1 == jtiles) {
@@ -895,53 +1012,9 @@ __global__ void __launch_bounds__(128 * (8 / PJ), PJ == 4 ? 1 : 2) k_tome_match_
     }
 }
 
-__global__ void k_tome_unpack(const unsigned long long* __restrict__ best, int na, float* __restrict__ node_max,
-                              int* __restrict__ node_idx, int* __restrict__ iota) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= na) return;
-    const unsigned long long b = best[i];
-    unsigned u = (unsigned)(b >> 32);
-    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
-    node_max[i] = b ? __uint_as_float(u) : __uint_as_float(0x7fc00000u);       // no finite score at all: NaN row
-    node_idx[i] = b ? (int)(0xffffffffu - (unsigned)(b & 0xffffffffu)) : 0;
-    iota[i] = i;
-}
-
 // ---------------------------------------------------------------------------------------------------
 // merge bookkeeping: sources (rank < r) grouped per destination b-token, in rank order
 // ---------------------------------------------------------------------------------------------------
-__global__ void k_tome_count(const int* __restrict__ order, const int* __restrict__ node_idx, int r, int* __restrict__ cnt) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < r) atomicAdd(cnt + node_idx[order[k]], 1);
-}
-
-__global__ void __launch_bounds__(1024) k_tome_scan(const int* __restrict__ cnt, int nb, int* __restrict__ off) {
-    // single workgroup exclusive scan (nb is a few 10^4 at most): every thread owns a contiguous run of elements, the
-    // workgroup scans the 1024 run totals once, and every thread writes the prefixes of its run
-    __shared__ int wsum[16];
-    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = nt >> 6;
-    const int per = (nb + nt - 1) / nt;
-    const int lo = min(tid * per, nb), hi = min(lo + per, nb);
-    int total = 0;
-    for (int i = lo; i < hi; ++i) total += cnt[i];
-    int inc = total;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += o;
-    }
-    if (lane == 63) wsum[wave] = inc;
-    __syncthreads();
-    int pre = inc - total;
-    for (int w = 0; w < wave; ++w) pre += wsum[w];
-    for (int i = lo; i < hi; ++i) { off[i] = pre; pre += cnt[i]; }
-    if (tid == nt - 1) {
-        int all = 0;
-        for (int w = 0; w < nwave; ++w) all += wsum[w];
-        off[nb] = all;
-    }
-}
-
 __global__ void k_tome_fill(const int* __restrict__ order, const int* __restrict__ node_idx, int r, const int* __restrict__ off,
                             int* __restrict__ cur, int* __restrict__ lists /* rank positions k */) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -952,22 +1025,21 @@ __global__ void k_tome_fill(const int* __restrict__ order, const int* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Ranking by counting (round 4): replaces k_tome_unpack + hipcub::DeviceRadixSort (4 launches) + k_tome_count for clips of up to
-// kRankMax a-tokens.  argsort(node_max, descending) with ties to the smaller index (tome_token_merger.py:37; the stable order the
-// radix sort produced):  rank_i = #{ j : key_j > key_i }  on the 64-bit keys  (order-preserving bits of the score << 32) | ~i,
-// which are all distinct.  12 544 a-tokens (T = 128) are 1.6e8 compares -- microseconds of VALU time -- against ~45 us of
-// launches and passes for the sort and its bookkeeping.  Workgroup (ib, js): 256 a-tokens (one per thread) against the js-th part
-// of the keys, staged through LDS in tiles and read back as broadcasts; partial counts meet in `rank` (zeroed) through atomics,
-// and the LAST part of an a-block to arrive (per-block arrival counter) turns the complete ranks into `order`, writes the
-// unpacked node_max / node_idx and counts the sources of every destination (rank < r) -- the old k_tome_count; the a-block that
-// completes last of all scans those counts (the old k_tome_scan).
+// Ranking by counting (round 4; round 6: the only ranking path -- it replaced a k_tome_unpack + hipcub::DeviceRadixSort + count + scan
+// chain of 8 launches, first for clips of up to 49 152 a-tokens, now for every length: both the ranking and the match are O(na^2) and
+// the ranking stays a few per cent of the match).  argsort(node_max, descending) with ties to the smaller index (tome_token_merger.py:37):
+//   rank_i = #{ j : key_j > key_i }  on the 64-bit keys  (order-preserving bits of the score << 32) | ~i,
+// which are all distinct.  12 544 a-tokens (T = 128) are 1.6e8 compares -- microseconds of VALU time.  Workgroup (ib, js): 256
+// a-tokens (one per thread) against the js-th part of the keys, staged through LDS in tiles and read back as broadcasts; partial
+// counts go to rank[js][i], and the LAST part of an a-block to arrive (per-block arrival counter) sums them, turns the complete ranks
+// into `order`, writes the unpacked node_max / node_idx and counts the sources of every destination (rank < r); the a-block that
+// completes last of all scans those counts.
 // ---------------------------------------------------------------------------------------------------
-constexpr int kRankMax = 49152;        // beyond that (T > ~500 frames of 196 tokens) the radix sort path is used
 constexpr int RK_I = 256;
 constexpr int kRankParts = 32;         // most key-range parts per a-block (partial ranks are [parts][na] ints of workspace)
 
 __device__ __forceinline__ unsigned long long tome_rank_key(unsigned long long b, int i) {
-    const unsigned ku = b ? (unsigned)(b >> 32) : 0xffc00000u;          // no finite score at all: a NaN row (sorts first, like the radix sort)
+    const unsigned ku = b ? (unsigned)(b >> 32) : 0xffc00000u;          // no finite score at all: a NaN row (sorts first)
     return ((unsigned long long)ku << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
 }
 
@@ -1023,7 +1095,7 @@ __global__ void __launch_bounds__(RK_I) k_tome_rank(const unsigned long long* __
     // agent-scope relaxed stores / loads below compile to global_store / global_load ... sc1 (write-through to / read from the device's
     // coherence point, past the CU's L1 and the XCD's L2 copy), the drain makes the payload leave before the arrival atomic, which is a
     // memory-side read-modify-write.  The library is built for gfx950 only (sttm_common.h refuses any other device target);
-    // test_tome_rank_by_counting_and_radix_sort_paths_are_bit_identical compares this kernel with the radix-sort path.
+    // test_tome_ranking_equals_a_stable_descending_argsort compares the order this kernel leaves with torch's stable argsort.
     // Everything that crosses workgroups here is an agent-scope atomic (performed at the device's coherence point) read back with
     // agent-scope loads: every wave drains its own (vmcnt), then ONE relaxed arrival -- no release / acquire fences, which on this
     // multi-XCD part are L2 write-backs + invalidates per workgroup (a __threadfence() here made the kernel 67 - 120 us).
@@ -1272,8 +1344,7 @@ __global__ void __launch_bounds__(256) k_tome_merge(const void* __restrict__ x, 
 
 struct TomePlan {
     int na, nb, D, Dp;
-    size_t off_ahat, off_bhat, off_best, off_nmax, off_nidx, off_iota, off_keys, off_order, off_cnt, off_cur, off_rank, off_arrive, off_off, off_parts,
-        off_lists, off_cub, cub_bytes, total;
+    size_t off_ahat, off_bhat, off_best, off_nmax, off_nidx, off_order, off_cnt, off_cur, off_rank, off_arrive, off_off, off_parts, off_lists, total;
 };
 
 static int tome_cu_count() {
@@ -1293,13 +1364,14 @@ static int tome_plan(int n, int C, int n_head, TomePlan* p) {
     if (n < 2 || C < 1 || n_head < 1 || C % n_head) return -1;
     p->na = (n + 1) / 2; p->nb = n / 2; p->D = C / n_head;
     p->Dp = (p->D + 63) / 64 * 64;                           // zero-padded to the widest k stage of the match kernels
+    // the 256-tile match kernels address a unit-row matrix through ONE buffer descriptor with 32-bit byte offsets (two 2-byte planes per
+    // element at most): clips beyond 2 GiB per matrix (fp32 C = 1024: over a million tokens) are refused, not wrapped around
+    if ((unsigned long long)p->na * p->Dp * 4ull >= (1ull << 31)) return -2;
     size_t o = 0;
     p->off_ahat = o; o = al(o + (size_t)p->na * p->Dp * 4);
     p->off_bhat = o; o = al(o + (size_t)(p->nb > 0 ? p->nb : 1) * p->Dp * 4);
     p->off_nmax = o; o = al(o + (size_t)p->na * 4);
     p->off_nidx = o; o = al(o + (size_t)p->na * 4);
-    p->off_iota = o; o = al(o + (size_t)p->na * 4);
-    p->off_keys = o; o = al(o + (size_t)p->na * 4);
     p->off_order = o; o = al(o + (size_t)p->na * 4);
     // ONE zeroed region [off_best, off_off): the packed best scores, the per-destination counts and cursors, the partial ranks and
     // the per-block arrival counters of the ranking kernel
@@ -1310,12 +1382,7 @@ static int tome_plan(int n, int C, int n_head, TomePlan* p) {
     p->off_arrive = o; o = al(o + (size_t)((p->na + RK_I - 1) / RK_I + 1) * 4);
     p->off_off = o; o = al(o + (size_t)(p->nb + 2) * 4);
     p->off_lists = o; o = al(o + (size_t)p->na * 4);
-    p->off_parts = o; o = al(o + (p->na <= kRankMax ? (size_t)kRankParts * p->na * 4 : 0));      // partial ranks [parts][na]
-    size_t cub = 0;
-    (void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, cub, (const float*)nullptr, (float*)nullptr, (const int*)nullptr,
-                                                 (int*)nullptr, p->na);
-    p->cub_bytes = cub;
-    p->off_cub = o; o = al(o + cub);
+    p->off_parts = o; o = al(o + (size_t)kRankParts * p->na * 4);      // partial ranks [parts][na]
     p->total = o;
     return 0;
 }
@@ -1338,7 +1405,7 @@ int sttm_tome_step(const void* x_, const float* size, const int64_t* idx, int n,
     if (dtype < 0 || dtype > 2) return STTM_ERR_ARG;
     if (!x_ || !workspace || !x_out_ || !size_out || !idx_out) return STTM_ERR_ARG;       // (idx == NULL: the identity, first iteration)
     TomePlan p;
-    if (tome_plan(n, C, n_head, &p) != 0) return STTM_ERR_ARG;
+    if (const int prc = tome_plan(n, C, n_head, &p)) return prc == -2 ? STTM_ERR_UNSUPPORTED : STTM_ERR_ARG;
     if (workspace_bytes < p.total) return STTM_ERR_ARG;
     if (r < 1 || r > p.nb) return STTM_ERR_ARG;              // callers clamp r = min(r, n // 2) like the reference
     char* ws = reinterpret_cast<char*>(workspace);
@@ -1347,8 +1414,6 @@ int sttm_tome_step(const void* x_, const float* size, const int64_t* idx, int n,
     unsigned long long* best = reinterpret_cast<unsigned long long*>(ws + p.off_best);
     float* nmax = reinterpret_cast<float*>(ws + p.off_nmax);
     int* nidx = reinterpret_cast<int*>(ws + p.off_nidx);
-    int* iota = reinterpret_cast<int*>(ws + p.off_iota);
-    float* keys = reinterpret_cast<float*>(ws + p.off_keys);
     int* order = reinterpret_cast<int*>(ws + p.off_order);
     int* cnt = reinterpret_cast<int*>(ws + p.off_cnt);
     int* cur = reinterpret_cast<int*>(ws + p.off_cur);
@@ -1420,6 +1485,8 @@ int sttm_tome_step(const void* x_, const float* size, const int64_t* idx, int n,
             else if (abl == 4) hipLaunchKernelGGL((k_tome_match_glds<2, 4, f16_t, 4>), dim3(js ? it * js : it), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
             else if (abl == 5) hipLaunchKernelGGL((k_tome_match_glds<2, 4, f16_t, 5>), dim3(js ? it * js : it), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
             else if (abl == 6) hipLaunchKernelGGL((k_tome_match_glds<2, 4, f16_t, 6>), dim3(js ? it * js : it), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
+            else if (abl == 8 && split == 7) hipLaunchKernelGGL((k_tome_match_glds<2, 3, f16_t, 8, 4>), dim3(js ? it * js : it), dim3(256), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
+            else if (abl == 8) hipLaunchKernelGGL((k_tome_match_glds<2, 3, f16_t, 8>), dim3(js ? it * js : it), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
             else
 #endif
             if (split == 7) hipLaunchKernelGGL((k_tome_match_glds<2, 3, f16_t, 0, 4>), dim3(js ? it * js : it), dim3(256), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best);
@@ -1444,9 +1511,9 @@ int sttm_tome_step(const void* x_, const float* size, const int64_t* idx, int n,
         pick_flat(it, js);
 #ifdef STTM_DEV
         const int abl16 = getenv("STTM_TOME_ABL") ? atoi(getenv("STTM_TOME_ABL")) : 0;
-        constexpr int ABL16A = 3, ABL16B = 4, ABL16C = 5, ABL4A = 1, ABL4B = 5, ABL4C = 6, ABL4D = 7;      // (four-wave form: 1 no DMA, 5 MFMAs alone, 6 + fragment reads, 7 no running max)
+        constexpr int ABL16A = 3, ABL16B = 4, ABL16C = 5, ABL4A = 1, ABL4B = 5, ABL4C = 6, ABL4D = 7, ABLSW = 8;      // (four-wave form: 1 no DMA, 5 MFMAs alone, 6 + fragment reads, 7 no running max; 8: the one-pass sweep, either form)
 #else
-        constexpr int abl16 = 0, ABL16A = 0, ABL16B = 0, ABL16C = 0, ABL4A = 0, ABL4B = 0, ABL4C = 0, ABL4D = 0;
+        constexpr int abl16 = 0, ABL16A = 0, ABL16B = 0, ABL16C = 0, ABL4A = 0, ABL4B = 0, ABL4C = 0, ABL4D = 0, ABLSW = 0;
 #endif
 #define STTM_TOME_16(TT)                                                                                                            \
         do {                                                                                                                        \
@@ -1457,6 +1524,8 @@ int sttm_tome_step(const void* x_, const float* size, const int64_t* idx, int n,
             if (big && abl16 == 3) hipLaunchKernelGGL((k_tome_match_glds<1, 1, TT, ABL16A>), dim3(js ? it * js : it), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best); \
             else if (big && abl16 == 4) hipLaunchKernelGGL((k_tome_match_glds<1, 1, TT, ABL16B>), dim3(js ? it * js : it), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best); \
             else if (big && abl16 == 5) hipLaunchKernelGGL((k_tome_match_glds<1, 1, TT, ABL16C>), dim3(js ? it * js : it), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best); \
+            else if (big && split == 7 && abl16 == 8) hipLaunchKernelGGL((k_tome_match_glds<1, 1, TT, ABLSW, 4>), dim3(js ? it * js : it), dim3(256), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best); \
+            else if (big && abl16 == 8) hipLaunchKernelGGL((k_tome_match_glds<1, 1, TT, ABLSW>), dim3(js ? it * js : it), dim3(512), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best); \
             else if (big && split == 7 && abl16 == 1) hipLaunchKernelGGL((k_tome_match_glds<1, 1, TT, ABL4A, 4>), dim3(js ? it * js : it), dim3(256), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best); \
             else if (big && split == 7 && abl16 == 5) hipLaunchKernelGGL((k_tome_match_glds<1, 1, TT, ABL4B, 4>), dim3(js ? it * js : it), dim3(256), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best); \
             else if (big && split == 7 && abl16 == 6) hipLaunchKernelGGL((k_tome_match_glds<1, 1, TT, ABL4C, 4>), dim3(js ? it * js : it), dim3(256), 2 * TG_BUF, stream, ap, bp, p.na, p.nb, p.Dp, js, best); \
@@ -1468,8 +1537,8 @@ int sttm_tome_step(const void* x_, const float* size, const int64_t* idx, int n,
         if (dtype == STTM_BF16) STTM_TOME_16(bf16_t); else STTM_TOME_16(f16_t);
 #undef STTM_TOME_16
     }
-    if (p.na <= kRankMax && tome_rank_mode() != 1) {
-        // ranking by counting (+ the scan, in its last workgroup) and the list fill (round 4): 2 launches instead of 8
+    {
+        // ranking by counting (+ the scan, in its last workgroup) and the list fill (round 4): 2 launches
         const int iblocks = (p.na + RK_I - 1) / RK_I;
         int js = (8 * n_cu + iblocks - 1) / iblocks;                    // ~8 four-wave workgroups per CU: the scalar key loads of a wave
         const int max_js = (p.na + 255) / 256;                          // are not pipelined, other waves cover them
@@ -1477,13 +1546,6 @@ int sttm_tome_step(const void* x_, const float* size, const int64_t* idx, int n,
         if (js > kRankParts) js = kRankParts;
         if (js < 1) js = 1;
         hipLaunchKernelGGL(k_tome_rank, dim3(iblocks * js), dim3(RK_I), 0, stream, best, p.na, js, r, rank, arrive, nmax, nidx, order, cnt, p.nb, off);
-        hipLaunchKernelGGL(k_tome_fill, dim3((r + 255) / 256), dim3(256), 0, stream, order, nidx, r, off, cur, lists);
-    } else {
-        hipLaunchKernelGGL(k_tome_unpack, dim3((p.na + 255) / 256), dim3(256), 0, stream, best, p.na, nmax, nidx, iota);
-        size_t cub = p.cub_bytes;
-        (void)hipcub::DeviceRadixSort::SortPairsDescending(ws + p.off_cub, cub, nmax, keys, iota, order, p.na, 0, 32, stream);
-        hipLaunchKernelGGL(k_tome_count, dim3((r + 255) / 256), dim3(256), 0, stream, order, nidx, r, cnt);
-        hipLaunchKernelGGL(k_tome_scan, dim3(1), dim3(1024), 0, stream, cnt, p.nb, off);
         hipLaunchKernelGGL(k_tome_fill, dim3((r + 255) / 256), dim3(256), 0, stream, order, nidx, r, off, cur, lists);
     }
     {

@@ -45,7 +45,7 @@ def _tome_video(x_tchw, prune_ratio, n_head):
                                 "(prune_ratio <= 0 is unusable in the reference)")
             nbytes = lib.sttm_tome_workspace_bytes(n, C, int(n_head))
             if nbytes == 0:
-                raise ValueError(f"bad ToMe configuration n={n} C={C} n_head={n_head}")
+                raise ValueError(f"bad ToMe configuration n={n} C={C} n_head={n_head} (or a clip beyond the 2 GiB unit-row limit of include/sttm_hip.h)")
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             x_out = torch.empty((n - r, C), dtype=x.dtype, device=dev)
             size_out = torch.empty(n - r, dtype=torch.float32, device=dev)

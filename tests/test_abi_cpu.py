@@ -120,6 +120,11 @@ def test_host_side_size_functions_of_the_baselines():
     assert lib.sttm_dycoke_out_rows(5, 49, 24) == 2 * 49 + 3 * 24
     # octree: root level outside [2, ..., side] -> no workspace (the wrapper raises IndexError)
     assert lib.sttm_octree_workspace_bytes(1, 14, 32, 0, 9) == 0 and lib.sttm_octree_workspace_bytes(1, 14, 32, 0, 0) > 0
+    # ToMe: bad shapes and clips beyond the 2 GiB unit-row matrix of the 256-tile match kernels (32-bit buffer offsets) are refused
+    assert lib.sttm_tome_workspace_bytes(35280, 1024, 1) > 0 and lib.sttm_tome_workspace_bytes(1, 1024, 1) == 0
+    assert lib.sttm_tome_workspace_bytes(35280, 1024, 3) == 0
+    assert lib.sttm_tome_workspace_bytes(1_040_000, 1024, 1) > 0 and lib.sttm_tome_workspace_bytes(1_050_000, 1024, 1) == 0
+    assert lib.sttm_tome_workspace_bytes(131_000, 8192, 1) > 0 and lib.sttm_tome_workspace_bytes(131_100, 8192, 1) == 0
 
 
 def test_configure_accepts_known_keys_only():

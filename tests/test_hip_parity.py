@@ -1176,41 +1176,42 @@ def test_tome_batch_over_side_streams_equals_per_video_calls():
     assert get_tome_features_batch([], 0.5) == [] and get_tome_features_batch(vids[:2], 0.5, "snippet") == [None, None]
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
-def test_tome_rank_by_counting_and_radix_sort_paths_are_bit_identical(dtype):
-    """`argsort(node_max, descending)` with ties to the smaller index is computed either by counting in one kernel (`tome_rank = 0`, the
-    default up to 49 152 a-tokens) or by the radix sort path (`tome_rank = 1`, the path of longer clips): same order, hence the same bits --
-    on sizes that are not multiples of the rank kernel's 256-token blocks, on clips with massive exact ties (16-bit scores; duplicated
-    tokens), with NaN rows (a zero token has a 0/0 unit row), and on a clip ABOVE the counting kernel's limit, where both settings must
-    take the radix path."""
-    from sttm_amd import _lib, get_tome_features
+@pytest.mark.parametrize("dtype,code", [(torch.float32, 0), (torch.bfloat16, 1)], ids=["f32", "bf16"])
+def test_tome_ranking_equals_a_stable_descending_argsort(dtype, code):
+    """`argsort(node_max, descending)` with ties to the smaller index (tome_token_merger.py:37) is computed by counting in one kernel, for
+    every clip length (round 6: the radix-sort path of clips above 49 152 a-tokens is gone).  Through the C ABI: the unmerged even tokens
+    come out in exactly the order of torch's stable descending argsort of the kernel's own best scores -- on sizes that are not multiples
+    of the rank kernel's 256-token blocks, with massive exact ties (16-bit scores; a duplicated frame), with NaN rows (a zero token has a
+    0/0 unit row; NaN sorts first), and on clips of 49 196 and 68 600 a-tokens."""
+    from sttm_amd import _lib
     from sttm_amd.synth import synth_video
+    lib = _lib.load()
     dev = _dev()
-    try:
-        cases = [(1, 256, 0.5), (3, 1024, 0.7), (11, 128, 0.85), (40, 256, 0.6), (128, 64, 0.5)]
-        for T, C, ratio in cases:
-            x = synth_video(T, C, 14, 14, seed=700 + T, dtype=dtype).to(dev)
-            if T == 11:
-                flat = x.permute(0, 2, 3, 1)
-                flat[2] = flat[1]                          # a whole frame duplicated: hundreds of exactly equal best scores
-                flat[5, 3, 4] = 0                          # a zero token: NaN unit row, NaN scores
-                flat[6, 0, 0] = 0
-            outs = []
-            for rank in (0, 1):
-                _lib.configure(tome_rank=rank)
-                outs.append(get_tome_features(x, ratio, "video"))
-            (f0, i0), (f1, i1) = outs
-            assert torch.equal(i0, i1), f"{dtype} T={T} C={C} r={ratio}: kept-token ids differ between the rank paths"
-            assert torch.equal(f0.view(torch.int32 if dtype == torch.float32 else torch.int16), f1.view(torch.int32 if dtype == torch.float32 else torch.int16))
-        # above kRankMax a-tokens (T = 502 frames of 196 tokens = 49 196 a-tokens): the radix path whatever the switch says
-        x = synth_video(502, 16, 14, 14, seed=777, dtype=dtype).to(dev)
-        _lib.configure(tome_rank=0)
-        fa, ia = get_tome_features(x, 0.5, "video")
-        _lib.configure(tome_rank=1)
-        fb, ib = get_tome_features(x, 0.5, "video")
-        assert torch.equal(ia, ib) and torch.equal(fa, fb) and ia.shape[0] == 502 * 196 // 2
-    finally:
-        _lib.configure(tome_rank=0)
+    for T, C, ratio in [(1, 256, 0.5), (3, 1024, 0.7), (11, 128, 0.85), (40, 256, 0.6), (128, 64, 0.5), (502, 16, 0.5), (700, 16, 0.3)]:
+        x = synth_video(T, C, 14, 14, seed=700 + T, dtype=dtype).to(dev)
+        flat = x.permute(0, 2, 3, 1)
+        if T == 11:
+            flat[2] = flat[1]                          # a whole frame duplicated: hundreds of exactly equal best scores
+            flat[5, 3, 4] = 0                          # a zero token: NaN unit row, NaN scores
+            flat[6, 0, 0] = 0
+        tok = flat.reshape(-1, C).contiguous()
+        n = tok.shape[0]
+        na = (n + 1) // 2
+        r = min(int(n * ratio), n // 2)
+        nbytes = lib.sttm_tome_workspace_bytes(n, C, 1)
+        assert nbytes > 0
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        xo = torch.empty((n - r, C), device=dev, dtype=dtype); so = torch.empty(n - r, device=dev); io = torch.empty(n - r, dtype=torch.int64, device=dev)
+        nmax = torch.empty(na, device=dev); nidx = torch.empty(na, dtype=torch.int32, device=dev)
+        rc = lib.sttm_tome_step(tok.data_ptr(), None, None, n, C, 1, r, code, ws.data_ptr(), nbytes, xo.data_ptr(), so.data_ptr(), io.data_ptr(),
+                                nmax.data_ptr(), nidx.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        _lib.raise_for(rc)
+        torch.cuda.synchronize()
+        order = torch.argsort(nmax, descending=True, stable=True)
+        assert torch.equal(io[:na - r], 2 * order[r:]), f"{dtype} T={T} C={C} r={r}: unmerged even tokens are not in stable descending order"
+        assert torch.equal(io[na - r:], 2 * torch.arange(n // 2, device=dev) + 1), f"{dtype} T={T}: odd tokens out of order"
+        if T == 11:
+            assert int(torch.isnan(nmax).sum()) >= 1 and bool(torch.isnan(nmax[order[0]]))
 
 
 @pytest.mark.parametrize("mode", [3, 4, 7], ids=["tile128", "tile256_dma", "tile256_four_waves"])

@@ -96,8 +96,8 @@ def test_headline_and_production_kernels_use_no_scratch(kernels, what, pattern):
 def test_four_wave_tome_kernels_keep_the_compiler_out_of_the_agprs():
     """csrc/tome.hip, TomeAcc: the four-wave match kernels name their 256 accumulator registers literally in inline assembly; a compiler
     spill into an AGPR (v_accvgpr_write) or a compiler copy out of one would corrupt / duplicate them silently.  The disassembly of the
-    built kernels must hold exactly the 256 v_accvgpr_read of TomeAcc::read (16 per block, one statement pair per block) and no
-    v_accvgpr_write / v_accvgpr_mov at all."""
+    built kernels must hold exactly the 512 v_accvgpr_read of TomeAcc::read (16 per block, one statement pair per block, once in each of
+    the two passes of the running max) and no v_accvgpr_write / v_accvgpr_mov at all."""
     lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sttm_amd", "lib", "libsttm_hip.so")
     if not os.path.exists(lib):
         pytest.skip("library not built")
@@ -127,6 +127,6 @@ def test_four_wave_tome_kernels_keep_the_compiler_out_of_the_agprs():
                 if "k_tome_match_glds" not in head or not re.search(r"ELi0ELi4EE", head):
                     continue
                 found += 1
-                assert len(re.findall(r"v_accvgpr_read_b32", blk)) == 256, head
+                assert len(re.findall(r"v_accvgpr_read_b32", blk)) == 512, head
                 assert not re.search(r"v_accvgpr_write|v_accvgpr_mov", blk), head
     assert found >= 3, "the four-wave ToMe match kernels (fp32 two-plane, bf16, fp16) are missing from the library"

@@ -10,6 +10,8 @@ T, C = int(os.environ.get("T", "128")), 1024
 x = synth_video(T, C, 14, 14, seed=3, device=dev, gen_device=dev)
 if os.environ.get("DTYPE"):                      # DTYPE=bfloat16 / float16: the one-plane match kernels
     x = x.to(getattr(torch, os.environ["DTYPE"]))
+if os.environ.get("CONST_INPUT"):                # every element 1: same instructions and counters, (almost) no operand toggling -- the DVFS probe
+    x = torch.ones_like(x)
 for ratio in (0.5, 0.7, 0.85):
     get_tome_features(x, ratio, "video")
     torch.cuda.synchronize()
