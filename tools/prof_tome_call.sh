@@ -4,7 +4,7 @@
 set -u
 TAG=${1:-tc}; export T=${2:-180}; export DTYPE=${3:-bfloat16}; REPO=$(pwd); export TMPDIR=/tmp; mkdir -p "$REPO/gpurun_out"
 cd /tmp; rm -rf /tmp/tc_t
-N_IT=8 timeout 600 rocprofv3 --kernel-trace -d /tmp/tc_t -o x -- python "$REPO/tools/bench_tome.py" > /tmp/tc.log 2>&1
+N_IT=8 timeout ${PROF_TIMEOUT:-600} rocprofv3 --kernel-trace -d /tmp/tc_t -o x -- python "$REPO/tools/bench_tome.py" > /tmp/tc.log 2>&1
 cd "$REPO"
 python - "$(find /tmp/tc_t -name '*.db' | head -1)" > "gpurun_out/${TAG}_tome_call_T${T}_${DTYPE}.md" <<'PY'
 import re, sqlite3, sys
